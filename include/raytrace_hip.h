@@ -1,0 +1,236 @@
+/*
+ * raytrace_hip.h -- C ABI of libraytrace_hip.so, the MI355X (gfx950) replacement for the reference's
+ * ray-trace + shade hot path (reference: source/opencl/raytrace.c + raytrace_opencl.c, boundary raytrace.h:37-106).
+ *
+ * Two layers, both extern "C", plain pointers and sizes only (no HIP, torch or C++ types):
+ *
+ *  (1) DROP-IN layer  -- exactly the symbols the untouched plugin sources (render.cpp, trianglelist.cpp,
+ *      writebmp.cpp) link against today, with the reference's names, argument order and error convention.
+ *      Replacing raytrace.c by this library needs no change to any caller.
+ *
+ *  (2) RESIDENT layer (rtHip*) -- the same path split into upload / render / read-back so a host can keep a scene
+ *      in HBM across frames, render a subset of 128x128 tiles (multi-GPU partition) and hand in device pointers.
+ *      The drop-in RaytraceAll() is implemented on top of it.
+ *
+ * Vector layouts are the reference's padded OpenCL host types
+ * (source/3rdparty/opencl-1.2/include/CL/cl_platform.h:501,725,1025): float3/int3 = 16 bytes (lane 3 is padding
+ * and is never read), float2/uint2 = 8 bytes, uchar3 = 4 bytes.  When <CL/cl.h> has been included first the
+ * cl_* names are used as-is, so this header can stand in for raytrace.h inside the plugin.
+ */
+#ifndef RAYTRACE_HIP_H
+#define RAYTRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <time.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __OPENCL_CL_H
+typedef int32_t  cl_int;
+typedef uint32_t cl_uint;
+typedef uint16_t cl_ushort;
+typedef uint8_t  cl_uchar;
+typedef int8_t   cl_char;
+typedef float    cl_float;
+typedef cl_uint  cl_bool;
+typedef union { cl_float s[2]; } __attribute__((aligned(8)))  cl_float2;
+typedef union { cl_uint  s[2]; } __attribute__((aligned(8)))  cl_uint2;
+typedef union { cl_int   s[2]; } __attribute__((aligned(8)))  cl_int2;
+typedef union { cl_float s[4]; } __attribute__((aligned(16))) cl_float4;
+typedef union { cl_int   s[4]; } __attribute__((aligned(16))) cl_int4;
+typedef union { cl_uchar s[4]; } __attribute__((aligned(4)))  cl_uchar4;
+typedef cl_float4 cl_float3;
+typedef cl_int4   cl_int3;
+typedef cl_uchar4 cl_uchar3;
+#define CL_FALSE 0
+#define CL_TRUE  1
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------
+ * (1) DROP-IN layer
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Replaces RaytraceAll (reference raytrace.h:58-106, raytrace.c:230-657).
+ * computationType: 0 = the reference's in-thread CPU loop -- NOT provided by this library (it is the reference's
+ * own code, raytrace.c:604-655): the call fails loudly and returns CL_FALSE.
+ * k in 1..N = MI355X device k-1; N+1 = all N devices, image split into 128x128 tiles (only offered when N>1).
+ * Blocking.  Caller owns every array; nothing is retained.  Output planes are zeroed first, like the reference's
+ * OpenCL branch (raytrace.c:476,481,486), then accumulated.  Returns non-zero on success (raytrace.c:656). */
+cl_bool RaytraceAll(cl_uint computationType,
+                    cl_uint2 cameraImageDimension,
+                    cl_float3 cameraEye,
+                    cl_float3 cameraEyeToTopLeftVector,
+                    cl_float3 cameraLeftToRightPixelSizeVector,
+                    cl_float3 cameraTopToBottomPixelSizeVector,
+                    cl_float cameraPixelSizeInv,
+                    cl_uint *cameraPixelTriangleListStart,
+                    cl_uint *cameraPixelTriangleListEnd,
+                    cl_uint *cameraPixelTriangleList,
+                    ptrdiff_t cameraPixelTriangleListSize,
+                    cl_uint sampleCount,
+                    cl_uint vertexCount,
+                    cl_float3 *vertex,
+                    cl_uint triangleCount,
+                    cl_int3 *triangleVertexIndex,
+                    cl_int *triangleMaterialId,
+                    cl_float2 *triangleUv,
+                    cl_float3 *triangleNormal,
+                    cl_int axesDivCount,
+                    cl_float3 *sceneBoxMin,
+                    cl_uint *scenePixelTriangleListStart,
+                    cl_uint *scenePixelTriangleList,
+                    cl_uint materialCount,
+                    cl_uint2 *materialImageSize,
+                    cl_int *materialImageStart,
+                    cl_uint texturesSize,
+                    cl_uchar3 *textures,
+                    cl_uint lightCount,
+                    cl_int *lightType,
+                    cl_float3 *lightPosition,
+                    cl_float3 *lightDirection,
+                    cl_float3 *lightColour,
+                    cl_float *lightRadius,
+                    cl_float *lightHalfAttenuationDistance,
+                    cl_ushort *outputRed,
+                    cl_ushort *outputGreen,
+                    cl_ushort *outputBlue);
+
+/* Device enumeration (reference raytrace.h:46-50, raytrace.c:74-153).  Name 0 is the literal
+ * "Local CPU single thread" (raytrace.c:138); names 1..N are "AMD HIP <device name>"; name N+1 (N>1 only) is
+ * "AMD HIP all N GPUs (tiled)".  InitOpenCL publishes the table last, like raytrace.c:117-120. */
+void    InitOpenCL(void);
+void    ResetComputationType(void);
+cl_bool GetIsComputationTypeUpdated(void);
+size_t  GetComputationTypeCount(void);
+cl_bool GetComputationTypeName(size_t id, size_t strLen, cl_char *str);
+
+/* Progress / timing polled by the GUI thread (reference raytrace.h:52-56, raytrace.c:156-173).  Progress stays
+ * below 1 until the caller sets it (raytrace.c:580,607,614); start time becomes non-zero when the kernel phase
+ * begins; relaxed atomics inside. */
+cl_float GetProgress(void);
+void     SetProgress(cl_float p);
+clock_t  GetStartTime(void);
+clock_t  GetEndTime(void);
+void     ResetTime(void);
+
+/* Math helpers other plugin translation units link against (reference raytrace.h:37-44; definitions
+ * raytrace.c:18-45 and raytrace_opencl.c:83-101,124-172,174-193).  fp32, no contraction, same operation order. */
+cl_float  dot(cl_float3 a, cl_float3 b);
+cl_float3 cross(cl_float3 a, cl_float3 b);
+cl_float3 normalize(cl_float3 v);
+cl_float3 vector(cl_float3 a, cl_float3 b);
+cl_float  bindf(cl_float value, cl_float a, cl_float b);
+cl_float  GetPointToLineSqLen(cl_float3 origin, cl_float3 destination, cl_float3 point);
+cl_bool   RayIntersectsTriangle(cl_float3 origin, cl_float3 ray, cl_float minDistance, cl_float maxDistance,
+                                cl_float3 a, cl_float3 b, cl_float3 c,
+                                cl_float *outRayMult, cl_float *outABL, cl_float *outACL);
+cl_int3   GetBoxAddress(cl_int axesDivCount, cl_float3 *boxMin, cl_float3 position);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * (2) RESIDENT layer
+ * ---------------------------------------------------------------------------------------------------------- */
+
+#define RT_HIP_TILE 128 /* tile edge in pixels: the reference's NDRange granule (raytrace.c:507) */
+
+/* Everything RaytraceAll receives except the device choice and the output planes (same meaning, same layouts). */
+typedef struct rtHipSceneDesc {
+    cl_uint   width, height;
+    cl_float  eye[4], eyeToTopLeft[4], leftToRight[4], topToBottom[4];
+    cl_float  pixelSizeInv;
+    const cl_uint *camStart, *camEnd, *camList;
+    uint64_t  camListSize;
+    cl_uint   sampleCount;
+    cl_uint   vertexCount;
+    const cl_float3 *vertex;
+    cl_uint   triangleCount;
+    const cl_int3 *triIndex;
+    const cl_int  *triMaterial;
+    const cl_float2 *triUv;
+    const cl_float3 *triNormal;
+    cl_int    axesDiv;
+    const cl_float3 *boxMin;
+    const cl_uint *gridStart, *gridList;
+    cl_uint   materialCount;
+    const cl_uint2 *matSize;
+    const cl_int   *matStart;
+    cl_uint   texturesSize;
+    const cl_uchar3 *textures;
+    cl_uint   lightCount;
+    const cl_int *lightType;
+    const cl_float3 *lightPos, *lightDir, *lightCol;
+    const cl_float *lightRadius, *lightHalfAtt;
+} rtHipSceneDesc;
+
+typedef struct rtHipScene rtHipScene; /* opaque: a scene resident in one GPU's HBM */
+
+/* Work counters of one render, for the algorithmic-byte model. */
+typedef struct rtHipStats {
+    uint64_t primarySamples, primaryCandidates, gridRays, gridCells, gridCandidates, shadedHits, texelFetches;
+} rtHipStats;
+
+/* Number of HIP devices (0 when none / no driver).  Never fails. */
+int rtHipDeviceCount(void);
+
+/* Last error text of the calling thread ("" when none). */
+const char *rtHipLastError(void);
+
+/* Uploads a scene to `device` and builds the device-side layout (pre-resolved triangle records etc.).
+ * tileCount/tileIds select the 128x128 tiles this scene instance will render (row-major tile ids); NULL/0 = all.
+ * Only those tiles' slices of the camera lists are uploaded.  Returns NULL on failure. */
+rtHipScene *rtHipSceneCreate(int device, const rtHipSceneDesc *desc, const cl_uint *tileIds, cl_uint tileCount);
+void        rtHipSceneDestroy(rtHipScene *scene);
+
+/* Bytes of HBM held by the scene. */
+uint64_t rtHipSceneBytes(const rtHipScene *scene);
+
+/* Renders all samples of the scene's tiles into its device-resident tile buffer
+ * ([tile][plane R,G,B][128*128] u16, tiles in the order given at creation).  Asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the scene's own stream).  Returns 0 on success. */
+int rtHipRenderTiles(rtHipScene *scene, void *stream);
+
+/* Same, with work counters (slower; never used inside a timed region).  Synchronous. */
+int rtHipRenderTilesCounted(rtHipScene *scene, rtHipStats *stats);
+
+/* Device pointer / size in bytes of the tile buffer (for RCCL gathers and peer copies). */
+void    *rtHipTileBuffer(rtHipScene *scene);
+uint64_t rtHipTileBufferBytes(const rtHipScene *scene);
+
+/* De-tiles `tileCount` tiles held in a device buffer laid out like rtHipTileBuffer into three row-major
+ * width x height u16 DEVICE planes (saturating add into what is there).  Used by the gather root. */
+int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIds, cl_uint tileCount,
+                cl_uint width, cl_uint height, void *planeR, void *planeG, void *planeB, void *stream);
+
+/* Blocks until the scene's work is done, then adds its tiles into three HOST planes (width*height u16 each). */
+int rtHipReadback(rtHipScene *scene, cl_ushort *outR, cl_ushort *outG, cl_ushort *outB);
+
+/* Waits for `stream` (NULL = scene stream). */
+int rtHipSync(rtHipScene *scene, void *stream);
+
+/* Average duration in milliseconds of the trace kernel over the launches recorded since the last call
+ * (HIP events on the launch stream), and the number of launches.  Returns 0 on success. */
+int rtHipKernelTime(rtHipScene *scene, double *avgMs, uint64_t *launches);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Host-side acceleration-structure builders: the producers of the hot path's list inputs
+ * (counterparts of CameraTriangleList::New, source/util/trianglelist.cpp:520-626, and SceneTriangleList::New,
+ * :655-737).  Same membership tests in the same fp32 arithmetic; memory comes from malloc and is released with
+ * rtHipFree.  threads<=0 = all hardware threads.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rtHipBuildCameraList(cl_uint width, cl_uint height, const cl_float eye[4], const cl_float eyeToTopLeft[4],
+                         const cl_float leftToRight[4], const cl_float topToBottom[4], cl_float pixelSizeInv,
+                         cl_uint triangleCount, const cl_float3 *vertex, const cl_int3 *triIndex, int threads,
+                         cl_uint **outStart, cl_uint **outEnd, cl_uint **outList, uint64_t *outListSize);
+
+int rtHipBuildSceneGrid(cl_uint vertexCount, cl_uint triangleCount, const cl_float3 *vertex, const cl_int3 *triIndex,
+                        int threads, cl_float3 outBoxMin[257], cl_uint **outStart, cl_uint **outList,
+                        uint64_t *outListSize);
+
+void rtHipFree(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACE_HIP_H */

@@ -1,0 +1,571 @@
+// rt_api.cpp -- host side of libraytrace_hip.so: the C ABI of include/raytrace_hip.h.
+//
+// Replaces the reference's dispatcher (source/opencl/raytrace.c): where that file creates 35 USE_HOST_PTR buffers,
+// recompiles the kernel and enqueues tiles x samples NDRanges per call (raytrace.c:330-556), this one uploads the
+// scene once into HBM, reshapes it on the device (rt_prepare_triangles) and issues ONE launch per frame and GPU.
+// There is no CPU fallback: without a HIP device every entry point that would compute fails with an error text.
+#include "raytrace_hip.h"
+#include "rt_device.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+extern "C" hipError_t rtk_launch_trace(const RtDevScene *scene, int counted, hipStream_t stream);
+extern "C" hipError_t rtk_launch_prepare(uint32_t triangleCount, const void *vertex, const void *triIndex, const void *triMaterial,
+                                         const void *triUv, const void *triNormal, float *triRec, float *triShade, hipStream_t stream);
+extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
+                                        uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return -1;
+}
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));              \
+    } while (0)
+
+} // namespace
+
+struct rtHipScene {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    RtDevScene dev{};
+    std::vector<void *> allocs;
+    uint64_t bytes = 0;
+    std::vector<cl_uint> tileIds;
+    uint32_t width = 0, height = 0, tilesX = 0;
+    // kernel timing: one event pair per launch since the last rtHipKernelTime
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t eventsUsed = 0;
+
+    template <class T> int upload(const T *src, uint64_t count, const T **dst, const char *what)
+    {
+        void *p = nullptr;
+        const uint64_t n = count ? count : 1;
+        HIP_OK(hipMalloc(&p, n * sizeof(T)));
+        allocs.push_back(p);
+        bytes += n * sizeof(T);
+        if (count) {
+            if (!src) return fail("%s: null pointer with %llu elements", what, (unsigned long long)count);
+            HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        }
+        *dst = (const T *)p;
+        return 0;
+    }
+    template <class T> int alloc(uint64_t count, T **dst)
+    {
+        void *p = nullptr;
+        const uint64_t n = count ? count : 1;
+        HIP_OK(hipMalloc(&p, n * sizeof(T)));
+        allocs.push_back(p);
+        bytes += n * sizeof(T);
+        *dst = (T *)p;
+        return 0;
+    }
+};
+
+namespace {
+
+int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds, cl_uint tileCount)
+{
+    if (!d) return fail("null scene description");
+    if (d->width == 0 || d->height == 0) return fail("empty image %ux%u", d->width, d->height);
+    if (d->sampleCount == 0) return fail("sampleCount must be >= 1");
+    if (d->axesDiv != RT_GRID_DIV) return fail("axesDivCount %d unsupported (the reference builds %d, trianglelist.h:110)", d->axesDiv, RT_GRID_DIV);
+    if ((uint64_t)d->width * d->height > 0xffffffffull) return fail("image too large");
+    HIP_OK(hipSetDevice(sc->device));
+    HIP_OK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+
+    const uint32_t tilesX = (d->width + RT_TILE - 1) / RT_TILE, tilesY = (d->height + RT_TILE - 1) / RT_TILE;
+    sc->width = d->width; sc->height = d->height; sc->tilesX = tilesX;
+    const bool allTiles = (tileIds == nullptr || tileCount == 0);
+    if (allTiles) {
+        sc->tileIds.resize((size_t)tilesX * tilesY);
+        for (uint32_t i = 0; i < tilesX * tilesY; ++i) sc->tileIds[i] = i;
+    } else {
+        sc->tileIds.assign(tileIds, tileIds + tileCount);
+        for (cl_uint t : sc->tileIds)
+            if (t >= tilesX * tilesY) return fail("tile id %u out of range (%u tiles)", t, tilesX * tilesY);
+    }
+    const uint32_t nt = (uint32_t)sc->tileIds.size();
+
+    RtDevScene &D = sc->dev;
+    for (int i = 0; i < 3; ++i) { D.eye[i] = d->eye[i]; D.topLeft[i] = d->eyeToTopLeft[i]; D.lr[i] = d->leftToRight[i]; D.tb[i] = d->topToBottom[i]; }
+    D.pixelSizeInv = d->pixelSizeInv;
+    D.width = d->width; D.height = d->height; D.sampleCount = d->sampleCount;
+    D.tileCount = nt; D.tilesX = tilesX;
+    D.triangleCount = d->triangleCount;
+
+    // --- per-pixel candidate lists, re-ordered tile-major; only this instance's tiles are shipped -------------
+    {
+        std::vector<cl_uint> lstart((size_t)nt * RT_TILE_PIXELS, 0), lend((size_t)nt * RT_TILE_PIXELS, 0);
+        std::vector<cl_uint> compact;
+        std::unordered_map<uint64_t, cl_uint> remap; // (start,end) of an aliased range -> offset in `compact`
+        const bool slice = !allTiles;
+        for (uint32_t s = 0; s < nt; ++s) {
+            const uint32_t tx = sc->tileIds[s] % tilesX, ty = sc->tileIds[s] / tilesX;
+            for (uint32_t ly = 0; ly < RT_TILE; ++ly) {
+                const uint32_t gy = ty * RT_TILE + ly;
+                if (gy >= d->height) break;
+                for (uint32_t lx = 0; lx < RT_TILE; ++lx) {
+                    const uint32_t gx = tx * RT_TILE + lx;
+                    if (gx >= d->width) break;
+                    const uint64_t p = (uint64_t)gy * d->width + gx;
+                    cl_uint a = d->camStart[p], b = d->camEnd[p];
+                    if (b < a) b = a;
+                    if ((uint64_t)b > d->camListSize) return fail("camera list range [%u,%u) of pixel %llu exceeds list size %llu", a, b, (unsigned long long)p, (unsigned long long)d->camListSize);
+                    const size_t li = (size_t)s * RT_TILE_PIXELS + ly * RT_TILE + lx;
+                    if (!slice) { lstart[li] = a; lend[li] = b; continue; }
+                    if (a == b) { lstart[li] = lend[li] = 0; continue; }
+                    const uint64_t key = ((uint64_t)a << 32) | b;
+                    auto it = remap.find(key);
+                    cl_uint at;
+                    if (it == remap.end()) {
+                        at = (cl_uint)compact.size();
+                        compact.insert(compact.end(), d->camList + a, d->camList + b);
+                        remap.emplace(key, at);
+                    } else at = it->second;
+                    lstart[li] = at; lend[li] = at + (b - a);
+                }
+            }
+        }
+        if (sc->upload(lstart.data(), lstart.size(), &D.camStart, "camStart")) return -1;
+        if (sc->upload(lend.data(), lend.size(), &D.camEnd, "camEnd")) return -1;
+        if (slice) { if (sc->upload(compact.data(), compact.size(), &D.camList, "camList")) return -1; }
+        else if (sc->upload(d->camList, d->camListSize, &D.camList, "camList")) return -1;
+        HIP_OK(hipStreamSynchronize(sc->stream)); // staging vectors die here
+    }
+    {
+        const cl_uint *ids = nullptr;
+        if (sc->upload(sc->tileIds.data(), nt, &ids, "tileIds")) return -1;
+        D.tileIds = ids;
+    }
+
+    // --- geometry: upload the ABI arrays, reshape on the device, drop the originals -------------------------------
+    {
+        for (uint32_t t = 0; t < d->triangleCount; ++t)
+            for (int k = 0; k < 3; ++k)
+                if ((uint32_t)d->triIndex[t].s[k] >= d->vertexCount) return fail("triangle %u references vertex %d of %u", t, d->triIndex[t].s[k], d->vertexCount);
+        void *dv = nullptr, *di = nullptr, *dm = nullptr, *du = nullptr, *dn = nullptr;
+        const uint64_t T = d->triangleCount ? d->triangleCount : 1, V = d->vertexCount ? d->vertexCount : 1;
+        HIP_OK(hipMalloc(&dv, V * 16)); HIP_OK(hipMalloc(&di, T * 16)); HIP_OK(hipMalloc(&dm, T * 4));
+        HIP_OK(hipMalloc(&du, T * 24)); HIP_OK(hipMalloc(&dn, T * 48));
+        if (d->vertexCount) HIP_OK(hipMemcpyAsync(dv, d->vertex, (uint64_t)d->vertexCount * 16, hipMemcpyHostToDevice, sc->stream));
+        if (d->triangleCount) {
+            HIP_OK(hipMemcpyAsync(di, d->triIndex, (uint64_t)d->triangleCount * 16, hipMemcpyHostToDevice, sc->stream));
+            HIP_OK(hipMemcpyAsync(dm, d->triMaterial, (uint64_t)d->triangleCount * 4, hipMemcpyHostToDevice, sc->stream));
+            HIP_OK(hipMemcpyAsync(du, d->triUv, (uint64_t)d->triangleCount * 24, hipMemcpyHostToDevice, sc->stream));
+            HIP_OK(hipMemcpyAsync(dn, d->triNormal, (uint64_t)d->triangleCount * 48, hipMemcpyHostToDevice, sc->stream));
+        }
+        float *rec = nullptr, *shade = nullptr;
+        if (sc->alloc<float>(T * 16, &rec) || sc->alloc<float>(T * 24, &shade)) return -1;
+        HIP_OK(rtk_launch_prepare(d->triangleCount, dv, di, dm, du, dn, rec, shade, sc->stream));
+        HIP_OK(hipStreamSynchronize(sc->stream));
+        HIP_OK(hipFree(dv)); HIP_OK(hipFree(di)); HIP_OK(hipFree(dm)); HIP_OK(hipFree(du)); HIP_OK(hipFree(dn));
+        D.triRec = rec; D.triShade = shade;
+        for (uint32_t t = 0; t < d->triangleCount; ++t)
+            if (d->triMaterial[t] >= (cl_int)d->materialCount) return fail("triangle %u uses material %d of %u", t, d->triMaterial[t], d->materialCount);
+    }
+
+    // --- grid ----------------------------------------------------------------------------------------------------
+    {
+        std::vector<float> planes(3 * (RT_GRID_DIV + 1));
+        for (int w = 0; w < 3; ++w)
+            for (int i = 0; i <= RT_GRID_DIV; ++i) planes[w * (RT_GRID_DIV + 1) + i] = d->boxMin[i].s[w];
+        if (sc->upload(planes.data(), planes.size(), &D.boxMin, "boxMin")) return -1;
+        const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
+        if (!d->gridStart) return fail("null scenePixelTriangleListStart");
+        const uint64_t listSize = d->gridStart[cells];
+        if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
+        if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
+        HIP_OK(hipStreamSynchronize(sc->stream));
+    }
+
+    // --- materials -------------------------------------------------------------------------------------------------
+    {
+        D.materialCount = d->materialCount;
+        D.texelCount = d->texturesSize ? d->texturesSize : 1;
+        if (sc->upload((const uint32_t *)d->matSize, (uint64_t)d->materialCount * 10, &D.matSize, "materialImageSize")) return -1;
+        if (sc->upload((const int32_t *)d->matStart, (uint64_t)d->materialCount * 5, &D.matStart, "materialImageStart")) return -1;
+        if (sc->upload((const uint8_t *)d->textures, (uint64_t)d->texturesSize * 4, &D.textures, "textures")) return -1;
+        for (uint32_t m = 0; m < d->materialCount * 5; ++m) {
+            const uint64_t w = d->matSize[m].s[0], h = d->matSize[m].s[1];
+            if (w && ((int64_t)d->matStart[m] < 0 || (uint64_t)d->matStart[m] + w * h > d->texturesSize))
+                return fail("material channel %u: %llux%llu texels at %d exceed the %u-texel atlas", m, (unsigned long long)w, (unsigned long long)h, d->matStart[m], d->texturesSize);
+        }
+        // bump: xPart/yPart = (float)sin(dh*PI_F/2.f), normalPart factors = (float)cos(...) (raytrace_opencl.c:251-253)
+        // with dh = hE/255.f - h0/255.f.  Only 256x256 byte pairs exist: tabulate with the HOST libm -- the library
+        // the reference's C path calls -- so the device result is that library's, bit for bit.
+        std::vector<float> tsin(65536), tcos(65536);
+        for (int e = 0; e < 256; ++e)
+            for (int h = 0; h < 256; ++h) {
+                const float fe = (float)e / 255.f, fh = (float)h / 255.f;
+                const float arg = (fe - fh) * 3.14159265f / 2.f;
+                tsin[(e << 8) | h] = (float)std::sin((double)arg);
+                tcos[(e << 8) | h] = (float)std::cos((double)arg);
+            }
+        if (sc->upload(tsin.data(), tsin.size(), &D.bumpSin, "bumpSin")) return -1;
+        if (sc->upload(tcos.data(), tcos.size(), &D.bumpCos, "bumpCos")) return -1;
+        HIP_OK(hipStreamSynchronize(sc->stream));
+    }
+
+    // --- lights -----------------------------------------------------------------------------------------------------
+    {
+        D.lightCount = d->lightCount;
+        std::vector<float> spread(d->lightCount ? d->lightCount : 1, 0.f);
+        for (uint32_t j = 0; j < d->lightCount; ++j) {
+            const float *ld = d->lightDir[j].s;
+            const float dd = ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2];
+            // raytrace_opencl.c:594 (double sin * double sqrt, then one rounding to float)
+            spread[j] = (float)(std::sin((double)((d->lightRadius[j] / 2.f) * 3.14159265f / 180.f)) * std::sqrt((double)dd));
+        }
+        if (sc->upload(d->lightType, d->lightCount, &D.lightType, "lightType")) return -1;
+        if (sc->upload((const float *)d->lightPos, (uint64_t)d->lightCount * 4, &D.lightPos, "lightPosition")) return -1;
+        if (sc->upload((const float *)d->lightDir, (uint64_t)d->lightCount * 4, &D.lightDir, "lightDirection")) return -1;
+        if (sc->upload((const float *)d->lightCol, (uint64_t)d->lightCount * 4, &D.lightCol, "lightColour")) return -1;
+        if (sc->upload(d->lightRadius, d->lightCount, &D.lightRadius, "lightRadius")) return -1;
+        if (sc->upload(d->lightHalfAtt, d->lightCount, &D.lightHalfAtt, "lightHalfAttenuationDistance")) return -1;
+        if (sc->upload(spread.data(), d->lightCount, &D.lightSpread, "lightSpread")) return -1;
+        HIP_OK(hipStreamSynchronize(sc->stream));
+    }
+
+    // --- outputs ---------------------------------------------------------------------------------------------------
+    {
+        uint16_t *buf = nullptr;
+        if (sc->alloc<uint16_t>((uint64_t)nt * 3 * RT_TILE_PIXELS, &buf)) return -1;
+        HIP_OK(hipMemsetAsync(buf, 0, (uint64_t)nt * 3 * RT_TILE_PIXELS * 2, sc->stream));
+        D.tileBuf = buf;
+        unsigned long long *st = nullptr;
+        if (sc->alloc<unsigned long long>(8, &st)) return -1;
+        HIP_OK(hipMemsetAsync(st, 0, 64, sc->stream));
+        D.stats = st;
+        HIP_OK(hipStreamSynchronize(sc->stream));
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rtHipDeviceCount(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *rtHipLastError(void) { return g_error.c_str(); }
+
+rtHipScene *rtHipSceneCreate(int device, const rtHipSceneDesc *desc, const cl_uint *tileIds, cl_uint tileCount)
+{
+    g_error.clear();
+    const int n = rtHipDeviceCount();
+    if (n <= 0) { fail("no HIP device available: libraytrace_hip has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= n) { fail("device %d out of range (%d HIP devices)", device, n); return nullptr; }
+    rtHipScene *sc = new rtHipScene();
+    sc->device = device;
+    if (scene_build(sc, desc, tileIds, tileCount) != 0) {
+        std::string keep = g_error;
+        rtHipSceneDestroy(sc);
+        g_error = keep;
+        return nullptr;
+    }
+    return sc;
+}
+
+void rtHipSceneDestroy(rtHipScene *sc)
+{
+    if (!sc) return;
+    if (sc->device >= 0) (void)hipSetDevice(sc->device);
+    if (sc->stream) (void)hipStreamSynchronize(sc->stream);
+    for (auto &e : sc->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void *p : sc->allocs) (void)hipFree(p);
+    if (sc->stream) (void)hipStreamDestroy(sc->stream);
+    delete sc;
+}
+
+uint64_t rtHipSceneBytes(const rtHipScene *sc) { return sc ? sc->bytes : 0; }
+
+int rtHipRenderTiles(rtHipScene *sc, void *stream)
+{
+    if (!sc) return fail("null scene");
+    HIP_OK(hipSetDevice(sc->device));
+    hipStream_t st = stream ? (hipStream_t)stream : sc->stream;
+    if (sc->eventsUsed == sc->events.size()) {
+        hipEvent_t a, b;
+        HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+        sc->events.emplace_back(a, b);
+    }
+    auto &ev = sc->events[sc->eventsUsed++];
+    HIP_OK(hipEventRecord(ev.first, st));
+    HIP_OK(rtk_launch_trace(&sc->dev, 0, st));
+    HIP_OK(hipEventRecord(ev.second, st));
+    return 0;
+}
+
+int rtHipRenderTilesCounted(rtHipScene *sc, rtHipStats *stats)
+{
+    if (!sc || !stats) return fail("null argument");
+    HIP_OK(hipSetDevice(sc->device));
+    HIP_OK(hipMemsetAsync(sc->dev.stats, 0, 64, sc->stream));
+    HIP_OK(rtk_launch_trace(&sc->dev, 1, sc->stream));
+    unsigned long long host[8] = { 0 };
+    HIP_OK(hipMemcpyAsync(host, sc->dev.stats, 64, hipMemcpyDeviceToHost, sc->stream));
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    stats->primarySamples = host[0]; stats->primaryCandidates = host[1]; stats->gridRays = host[2]; stats->gridCells = host[3];
+    stats->gridCandidates = host[4]; stats->shadedHits = host[5]; stats->texelFetches = host[6];
+    return 0;
+}
+
+void *rtHipTileBuffer(rtHipScene *sc) { return sc ? (void *)sc->dev.tileBuf : nullptr; }
+uint64_t rtHipTileBufferBytes(const rtHipScene *sc) { return sc ? (uint64_t)sc->tileIds.size() * 3 * RT_TILE_PIXELS * 2 : 0; }
+
+int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIds, cl_uint tileCount, cl_uint width, cl_uint height,
+                void *planeR, void *planeG, void *planeB, void *stream)
+{
+    if (!tileBuffer || !tileIds || !planeR || !planeG || !planeB) return fail("null argument");
+    if (width == 0 || height == 0) return fail("empty image");
+    HIP_OK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t tilesX = (width + RT_TILE - 1) / RT_TILE, tilesY = (height + RT_TILE - 1) / RT_TILE;
+    for (cl_uint i = 0; i < tileCount; ++i)
+        if (tileIds[i] >= tilesX * tilesY) return fail("tile id %u out of range", tileIds[i]);
+    cl_uint *dIds = nullptr;
+    HIP_OK(hipMalloc((void **)&dIds, (size_t)(tileCount ? tileCount : 1) * 4));
+    hipError_t e = hipMemcpyAsync(dIds, tileIds, (size_t)tileCount * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = rtk_launch_detile(tileBuffer, dIds, tileCount, width, height, tilesX, planeR, planeG, planeB, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dIds);
+    if (e != hipSuccess) return fail("detile failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int rtHipSync(rtHipScene *sc, void *stream)
+{
+    if (!sc) return fail("null scene");
+    HIP_OK(hipSetDevice(sc->device));
+    HIP_OK(hipStreamSynchronize(stream ? (hipStream_t)stream : sc->stream));
+    return 0;
+}
+
+int rtHipReadback(rtHipScene *sc, cl_ushort *outR, cl_ushort *outG, cl_ushort *outB)
+{
+    if (!sc || !outR || !outG || !outB) return fail("null argument");
+    HIP_OK(hipSetDevice(sc->device));
+    HIP_OK(hipDeviceSynchronize());
+    const size_t nt = sc->tileIds.size();
+    std::vector<uint16_t> host(nt * 3 * RT_TILE_PIXELS);
+    HIP_OK(hipMemcpy(host.data(), sc->dev.tileBuf, host.size() * 2, hipMemcpyDeviceToHost));
+    cl_ushort *planes[3] = { outR, outG, outB };
+    for (size_t s = 0; s < nt; ++s) {
+        const uint32_t tx = sc->tileIds[s] % sc->tilesX, ty = sc->tileIds[s] / sc->tilesX;
+        for (int c = 0; c < 3; ++c)
+            for (uint32_t ly = 0; ly < RT_TILE; ++ly) {
+                const uint32_t gy = ty * RT_TILE + ly;
+                if (gy >= sc->height) break;
+                const uint16_t *src = host.data() + (s * 3 + c) * RT_TILE_PIXELS + ly * RT_TILE;
+                cl_ushort *dst = planes[c] + (size_t)gy * sc->width + tx * RT_TILE;
+                const uint32_t n = std::min<uint32_t>(RT_TILE, sc->width - tx * RT_TILE);
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t v = (uint32_t)dst[i] + src[i]; // saturating accumulate (raytrace_opencl.c:729-740)
+                    dst[i] = (cl_ushort)(v > 0xFFFFu ? 0xFFFFu : v);
+                }
+            }
+    }
+    return 0;
+}
+
+int rtHipKernelTime(rtHipScene *sc, double *avgMs, uint64_t *launches)
+{
+    if (!sc || !avgMs || !launches) return fail("null argument");
+    HIP_OK(hipSetDevice(sc->device));
+    double total = 0.0;
+    for (size_t i = 0; i < sc->eventsUsed; ++i) {
+        HIP_OK(hipEventSynchronize(sc->events[i].second));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, sc->events[i].first, sc->events[i].second));
+        total += ms;
+    }
+    *launches = sc->eventsUsed;
+    *avgMs = sc->eventsUsed ? total / (double)sc->eventsUsed : 0.0;
+    sc->eventsUsed = 0;
+    return 0;
+}
+
+// ---- drop-in layer ---------------------------------------------------------------------------------------------
+
+// device table, published last like raytrace.c:117-120
+static std::atomic<cl_bool> g_tableReady{ CL_FALSE };
+static std::atomic<int> g_deviceCount{ 0 };
+static char g_deviceName[256][256];
+static std::mutex g_tableMutex;
+
+void InitOpenCL(void)
+{
+    std::lock_guard<std::mutex> lock(g_tableMutex);
+    char names[256][256];
+    int n = rtHipDeviceCount();
+    if (n > 254) n = 254;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        memset(&prop, 0, sizeof prop);
+        if (hipGetDeviceProperties(&prop, i) != hipSuccess) strcpy(prop.name, "unknown");
+        snprintf(names[i], 256, "AMD HIP %.200s #%d", prop.name, i);
+    }
+    int entries = n;
+    if (n > 1) snprintf(names[entries++], 256, "AMD HIP all %d GPUs (tiled)", n);
+    memcpy(g_deviceName, names, sizeof(names[0]) * (size_t)entries);
+    g_deviceCount.store(entries, std::memory_order_relaxed);
+    g_tableReady.store(CL_TRUE, std::memory_order_release);
+}
+
+void ResetComputationType(void)
+{
+    if (g_tableReady.load(std::memory_order_acquire)) {
+        g_tableReady.store(CL_FALSE, std::memory_order_relaxed);
+        g_deviceCount.store(0, std::memory_order_relaxed);
+    }
+}
+
+cl_bool GetIsComputationTypeUpdated(void) { return g_tableReady.load(std::memory_order_acquire); }
+
+size_t GetComputationTypeCount(void) { return 1 + (size_t)g_deviceCount.load(std::memory_order_relaxed); }
+
+cl_bool GetComputationTypeName(size_t id, size_t strLen, cl_char *str)
+{
+    if (!str) return CL_FALSE;
+    if (0 == id--) {
+        static const char cpu[] = "Local CPU single thread"; // raytrace.c:138
+        if (strlen(cpu) <= strLen) { strcpy((char *)str, cpu); return CL_TRUE; }
+    } else if (id < (size_t)g_deviceCount.load(std::memory_order_relaxed)) {
+        if (strlen(g_deviceName[id]) <= strLen) {
+            memcpy(str, g_deviceName[id], std::min<size_t>(256, strLen)); // raytrace.c:147
+            return CL_TRUE;
+        }
+    }
+    return CL_FALSE;
+}
+
+static std::atomic<float> g_progress{ 0.f };
+static std::atomic<long> g_startTime{ 0 }, g_endTime{ 0 };
+
+cl_float GetProgress(void) { return g_progress.load(std::memory_order_relaxed); }
+void SetProgress(cl_float p) { g_progress.store(p, std::memory_order_relaxed); }
+clock_t GetStartTime(void) { return (clock_t)g_startTime.load(std::memory_order_relaxed); }
+clock_t GetEndTime(void) { return (clock_t)g_endTime.load(std::memory_order_relaxed); }
+void ResetTime(void) { g_startTime.store(0, std::memory_order_relaxed); g_endTime.store(0, std::memory_order_relaxed); }
+
+cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_float3 cameraEye, cl_float3 cameraEyeToTopLeftVector,
+                    cl_float3 cameraLeftToRightPixelSizeVector, cl_float3 cameraTopToBottomPixelSizeVector, cl_float cameraPixelSizeInv,
+                    cl_uint *cameraPixelTriangleListStart, cl_uint *cameraPixelTriangleListEnd, cl_uint *cameraPixelTriangleList,
+                    ptrdiff_t cameraPixelTriangleListSize, cl_uint sampleCount, cl_uint vertexCount, cl_float3 *vertex,
+                    cl_uint triangleCount, cl_int3 *triangleVertexIndex, cl_int *triangleMaterialId, cl_float2 *triangleUv,
+                    cl_float3 *triangleNormal, cl_int axesDivCount, cl_float3 *sceneBoxMin, cl_uint *scenePixelTriangleListStart,
+                    cl_uint *scenePixelTriangleList, cl_uint materialCount, cl_uint2 *materialImageSize, cl_int *materialImageStart,
+                    cl_uint texturesSize, cl_uchar3 *textures, cl_uint lightCount, cl_int *lightType, cl_float3 *lightPosition,
+                    cl_float3 *lightDirection, cl_float3 *lightColour, cl_float *lightRadius, cl_float *lightHalfAttenuationDistance,
+                    cl_ushort *outputRed, cl_ushort *outputGreen, cl_ushort *outputBlue)
+{
+    g_error.clear();
+    if (computationType == 0) {
+        // The reference's id 0 is its own in-thread C loop (raytrace.c:604-655).  This library is the device path
+        // only; falling back to a CPU here would hide a missing GPU.  Fail loudly.
+        fail("RaytraceAll: computationType 0 (\"Local CPU single thread\") is the reference's own C path and is not "
+             "provided by libraytrace_hip; pick a HIP device (computationType >= 1)");
+        fprintf(stderr, "libraytrace_hip: %s\n", g_error.c_str());
+        return CL_FALSE;
+    }
+    const int n = rtHipDeviceCount();
+    const bool all = (n > 1 && computationType == (cl_uint)n + 1);
+    if (n <= 0 || (!all && computationType > (cl_uint)n)) {
+        fail("RaytraceAll: computationType %u but %d HIP device(s) present", computationType, n);
+        fprintf(stderr, "libraytrace_hip: %s\n", g_error.c_str());
+        return CL_FALSE;
+    }
+    if (!outputRed || !outputGreen || !outputBlue) { fail("RaytraceAll: null output plane"); return CL_FALSE; }
+
+    rtHipSceneDesc d;
+    memset(&d, 0, sizeof d);
+    d.width = cameraImageDimension.s[0]; d.height = cameraImageDimension.s[1];
+    for (int i = 0; i < 3; ++i) {
+        d.eye[i] = cameraEye.s[i]; d.eyeToTopLeft[i] = cameraEyeToTopLeftVector.s[i];
+        d.leftToRight[i] = cameraLeftToRightPixelSizeVector.s[i]; d.topToBottom[i] = cameraTopToBottomPixelSizeVector.s[i];
+    }
+    d.pixelSizeInv = cameraPixelSizeInv;
+    d.camStart = cameraPixelTriangleListStart; d.camEnd = cameraPixelTriangleListEnd; d.camList = cameraPixelTriangleList;
+    d.camListSize = cameraPixelTriangleListSize < 0 ? 0 : (uint64_t)cameraPixelTriangleListSize;
+    d.sampleCount = sampleCount;
+    d.vertexCount = vertexCount; d.vertex = vertex;
+    d.triangleCount = triangleCount; d.triIndex = triangleVertexIndex; d.triMaterial = triangleMaterialId;
+    d.triUv = triangleUv; d.triNormal = triangleNormal;
+    d.axesDiv = axesDivCount; d.boxMin = sceneBoxMin; d.gridStart = scenePixelTriangleListStart; d.gridList = scenePixelTriangleList;
+    d.materialCount = materialCount; d.matSize = materialImageSize; d.matStart = materialImageStart;
+    d.texturesSize = texturesSize; d.textures = textures;
+    d.lightCount = lightCount; d.lightType = lightType; d.lightPos = lightPosition; d.lightDir = lightDirection;
+    d.lightCol = lightColour; d.lightRadius = lightRadius; d.lightHalfAtt = lightHalfAttenuationDistance;
+
+    // the OpenCL branch zeroes the planes before accumulating (raytrace.c:476,481,486)
+    const size_t P = (size_t)d.width * d.height;
+    memset(outputRed, 0, P * sizeof(cl_ushort));
+    memset(outputGreen, 0, P * sizeof(cl_ushort));
+    memset(outputBlue, 0, P * sizeof(cl_ushort));
+
+    const int first = all ? 0 : (int)computationType - 1, count = all ? n : 1;
+    const uint32_t tiles = ((d.width + RT_TILE - 1) / RT_TILE) * ((d.height + RT_TILE - 1) / RT_TILE);
+    std::vector<rtHipScene *> scenes((size_t)count, nullptr);
+    bool ok = true;
+    for (int g = 0; g < count && ok; ++g) {
+        std::vector<cl_uint> mine;
+        if (count > 1) {
+            for (uint32_t t = (uint32_t)g; t < tiles; t += (uint32_t)count) mine.push_back(t); // round-robin tile deal
+            if (mine.empty()) continue;
+        }
+        scenes[g] = rtHipSceneCreate(first + g, &d, mine.empty() ? nullptr : mine.data(), (cl_uint)mine.size());
+        ok = scenes[g] != nullptr;
+    }
+    g_progress.store(0.f, std::memory_order_relaxed);
+    const long t0 = (long)clock();
+    g_startTime.store(t0 ? t0 : 1, std::memory_order_relaxed); // must read non-zero once the kernel phase begins
+    g_endTime.store(t0 ? t0 : 1, std::memory_order_relaxed);
+    for (int g = 0; g < count && ok; ++g)
+        if (scenes[g]) ok = rtHipRenderTiles(scenes[g], nullptr) == 0;
+    int done = 0;
+    for (int g = 0; g < count && ok; ++g) {
+        if (!scenes[g]) continue;
+        ok = rtHipReadback(scenes[g], outputRed, outputGreen, outputBlue) == 0;
+        g_progress.store(0.999f * (float)++done / (float)count, std::memory_order_relaxed); // capped like raytrace.c:580
+    }
+    std::string keep = g_error;
+    for (rtHipScene *s : scenes) rtHipSceneDestroy(s);
+    g_error = keep;
+    g_endTime.store((long)clock(), std::memory_order_relaxed);
+    if (!ok) fprintf(stderr, "libraytrace_hip: RaytraceAll failed: %s\n", g_error.c_str());
+    return ok ? CL_TRUE : CL_FALSE;
+}
+
+} // extern "C"

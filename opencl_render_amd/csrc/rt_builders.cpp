@@ -1,0 +1,357 @@
+// rt_builders.cpp -- host-side producers of the hot path's list inputs.
+//
+// Counterparts of the reference's CameraTriangleList::New (source/util/trianglelist.cpp:520-626) and
+// SceneTriangleList::New (:655-737).  The membership tests are restated in the same fp32 arithmetic and
+// evaluation order (FillRectangle :131-217, Cull :381-430, BoxIntersectsTriangle :433-449, FillCube :452-503,
+// quantile planes :657-678), so the lists hold the same (cell, triangle) pairs in the same ascending order.
+// What is NOT taken over is the reference's strategy: no 2 GiB u64 key scratch + quicksort (:522-523,:565,
+// :681-682,:707) and no 2 MiB bitset memset per triangle (:457).  Pairs are binned with a count/prefix/fill
+// pass, and the flood fill clears only the bits it set, which turns the 61 s grid build of a 1 M-triangle
+// soup into seconds and lets triangles be processed on all host threads.
+//
+// Parity note: trianglelist.cpp cannot be compiled here (it needs the Maxon SDK's c4d.h), so these builders are
+// pinned by restatement only ("parity unpinned" in DESIGN.md).  The trace kernel does not depend on that: any
+// lists are just inputs to it, and the oracle consumes the very same arrays.
+#include "raytrace_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct F2 { float x, y; };
+struct F3 { float x, y, z; };
+
+inline F3 ld3(const cl_float3 &v) { return F3{ v.s[0], v.s[1], v.s[2] }; }
+inline float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }              // raytrace.c:18-20
+inline F3 cross3(F3 a, F3 b) { return F3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; } // :21-27
+
+// x86-64 float/double -> unsigned conversions as MSVC/gcc emit them (cvttss2si r64 + truncate to 32 bits):
+// negative values wrap, NaN/overflow give 0 in the low word.
+inline uint32_t to_u32(double v)
+{
+    if (!(v > -9223372036854775808.0 && v < 9223372036854775808.0)) return 0u;
+    return (uint32_t)(int64_t)v;
+}
+
+int hw_threads(int threads)
+{
+    if (threads > 0) return threads;
+    unsigned n = std::thread::hardware_concurrency();
+    return n ? (int)n : 1;
+}
+
+template <class Fn> void parallel_chunks(int threads, uint64_t n, Fn fn)
+{
+    threads = (int)std::min<uint64_t>((uint64_t)hw_threads(threads), std::max<uint64_t>(1, n));
+    if (threads <= 1) { fn(0, (uint64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
+        pool.emplace_back([=] { fn(t, lo, hi); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// ---- camera lists -------------------------------------------------------------------------------------------
+
+struct Camera { F3 eye, topLeft, lr, tb; float pixelSizeInv; };
+
+// trianglelist.cpp:74-90
+F2 camera_position(const Camera &c, F3 v)
+{
+    float invSq = c.pixelSizeInv * c.pixelSizeInv;
+    F3 ev{ v.x - c.eye.x, v.y - c.eye.y, v.z - c.eye.z };
+    F3 sn = cross3(c.lr, c.tb);
+    float scale = dot3(c.topLeft, sn) / dot3(ev, sn);
+    F3 tv{ scale * ev.x - c.topLeft.x, scale * ev.y - c.topLeft.y, scale * ev.z - c.topLeft.z };
+    return F2{ dot3(c.lr, tv) * invSq, dot3(c.tb, tv) * invSq };
+}
+
+// trianglelist.cpp:131-217.  Calls emit(pixel) for every pixel whose candidate list receives the triangle.
+template <class Emit> void fill_rectangle(uint32_t W, uint32_t H, F2 a, F2 b, F2 c, Emit emit)
+{
+    F2 ab{ b.x - a.x, b.y - a.y }, bc{ c.x - b.x, c.y - b.y }, ca{ a.x - c.x, a.y - c.y };
+    // slopes; division by zero fails the edge tests by design (:143-150)
+    F2 abS, bcS, caS;
+    abS.x = ab.x / ab.y; abS.y = 1.f / abS.x;
+    bcS.x = bc.x / bc.y; bcS.y = 1.f / bcS.x;
+    caS.x = ca.x / ca.y; caS.y = 1.f / caS.x;
+
+    // bounding rectangle clipped to the image (:153-157); fmin/fmax are the double functions on promoted floats
+    uint32_t x0 = to_u32(std::fmax(0.0, std::fmin(std::fmin((double)a.x, (double)b.x), std::fmin((double)c.x, (double)(float)(W - 1)))));
+    uint32_t y0 = to_u32(std::fmax(0.0, std::fmin(std::fmin((double)a.y, (double)b.y), std::fmin((double)c.y, (double)(float)(H - 1)))));
+    uint32_t x1 = to_u32(std::fmin((double)(float)(W - 1), std::fmax(std::fmax((double)a.x, (double)b.x), std::fmax((double)c.x, 0.0))));
+    uint32_t y1 = to_u32(std::fmin((double)(float)(H - 1), std::fmax(std::fmax((double)a.y, (double)b.y), std::fmax((double)c.y, 0.0))));
+
+    const uint32_t ax = to_u32(std::floor((double)a.x)), ay = to_u32(std::floor((double)a.y));
+    // the pixel holding vertex a, if on screen (:160-162)
+    if (0.f <= a.x && a.x < (float)W && 0.f <= a.y && a.y < (float)H)
+        emit((uint64_t)std::floor((double)a.x) + (uint64_t)std::floor((double)a.y) * (uint64_t)W);
+
+    for (uint32_t x = x0; x <= x1; ++x) {
+        for (uint32_t y = y0; y <= y1; ++y) {
+            if (x == ax && y == ay) continue;
+            const float fx = (float)x, fy = (float)y;
+            // where each edge crosses this pixel's row/column lines (:169-181)
+            float ab0 = a.x + (fy - a.y) * abS.x, ab1 = a.y + (fx - a.x) * abS.y, ab2 = ab0 + abS.x, ab3 = ab1 + abS.y;
+            float bc0 = b.x + (fy - b.y) * bcS.x, bc1 = b.y + (fx - b.x) * bcS.y, bc2 = bc0 + bcS.x, bc3 = bc1 + bcS.y;
+            float ca0 = c.x + (fy - c.y) * caS.x, ca1 = c.y + (fx - c.x) * caS.y, ca2 = ca0 + caS.x, ca3 = ca1 + caS.y;
+            bool edge =
+                ((0.f <= (a.x - ab0) * (ab0 - b.x)) & (x == to_u32(ab0))) | ((0.f <= (a.x - ab2) * (ab2 - b.x)) & (x == to_u32(ab2))) |
+                ((0.f <= (a.y - ab1) * (ab1 - b.y)) & (y == to_u32(ab1))) | ((0.f <= (a.y - ab3) * (ab3 - b.y)) & (y == to_u32(ab3))) |
+                ((0.f <= (b.x - bc0) * (bc0 - c.x)) & (x == to_u32(bc0))) | ((0.f <= (b.x - bc2) * (bc2 - c.x)) & (x == to_u32(bc2))) |
+                ((0.f <= (b.y - bc1) * (bc1 - c.y)) & (y == to_u32(bc1))) | ((0.f <= (b.y - bc3) * (bc3 - c.y)) & (y == to_u32(bc3))) |
+                ((0.f <= (c.x - ca0) * (ca0 - a.x)) & (x == to_u32(ca0))) | ((0.f <= (c.x - ca2) * (ca2 - a.x)) & (x == to_u32(ca2))) |
+                ((0.f <= (c.y - ca1) * (ca1 - a.y)) & (y == to_u32(ca1))) | ((0.f <= (c.y - ca3) * (ca3 - a.y)) & (y == to_u32(ca3)));
+            if (edge) {
+                emit((uint64_t)x + (uint64_t)y * (uint64_t)W);
+            } else {
+                // pixel corner inside the triangle: same-sign cross products (:197-211)
+                float axx = fx - a.x, axy = fy - a.y, bxx = fx - b.x, bxy = fy - b.y, cxx = fx - c.x, cxy = fy - c.y;
+                float k1 = ab.x * axy - ab.y * axx, k2 = bc.x * bxy - bc.y * bxx, k3 = ca.x * cxy - ca.y * cxx;
+                if ((0 <= k1 * k2) & (0 <= k2 * k3)) emit((uint64_t)x + (uint64_t)y * (uint64_t)W);
+            }
+        }
+    }
+}
+
+// ---- scene grid ---------------------------------------------------------------------------------------------
+
+constexpr int DIV = 256; // trianglelist.h:110
+
+// trianglelist.cpp:381-430 (Sutherland-Hodgman step with in-place insert, then removal of the outside points)
+bool cull(bool isMax, float limit, int dim, int *count, float poly[16][3])
+{
+    bool fresh[16] = { false };
+    for (int i = 0; i < *count; ++i) {
+        int nx = (i + 1) % *count;
+        float di = limit - poly[i][dim];
+        float dn = limit - poly[nx][dim];
+        if (di * dn < 0.f) {
+            float e0 = poly[nx][0] - poly[i][0], e1 = poly[nx][1] - poly[i][1], e2 = poly[nx][2] - poly[i][2];
+            float e[3] = { e0, e1, e2 };
+            float pct = di / e[dim];
+            int at = i + 1;
+            for (int j = (*count)++; at < j; --j) { poly[j][0] = poly[j - 1][0]; poly[j][1] = poly[j - 1][1]; poly[j][2] = poly[j - 1][2]; }
+            poly[at][0] = poly[i][0] + pct * e0;
+            poly[at][1] = poly[i][1] + pct * e1;
+            poly[at][2] = poly[i][2] + pct * e2;
+            fresh[at] = true;
+            i = at;
+        }
+    }
+    for (int i = 0; i < *count; ++i) {
+        bool outside = isMax ? (limit < poly[i][dim]) : (poly[i][dim] < limit);
+        if (!fresh[i] && outside) {
+            int k = (*count)--;
+            for (int j = i + 1; j < k; ++j) {
+                poly[j - 1][0] = poly[j][0]; poly[j - 1][1] = poly[j][1]; poly[j - 1][2] = poly[j][2];
+                fresh[j - 1] = fresh[j];
+            }
+            --i;
+        }
+    }
+    return 0 < *count;
+}
+
+// trianglelist.cpp:433-449
+bool box_hits_triangle(const float lo[3], const float hi[3], F3 a, F3 b, F3 c)
+{
+    int n = 3;
+    float poly[16][3] = { { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z } };
+    return cull(false, lo[0], 0, &n, poly) && cull(false, lo[1], 1, &n, poly) && cull(false, lo[2], 2, &n, poly) &&
+           cull(true, hi[0], 0, &n, poly) && cull(true, hi[1], 1, &n, poly) && cull(true, hi[2], 2, &n, poly);
+}
+
+// raytrace_opencl.c:174-193
+void box_address(const float (*bm)[4], F3 p, int cell[3])
+{
+    int cx = 0, cy = 0, cz = 0;
+    for (int div = DIV / 2; div >= 1; div /= 2) {
+        if (bm[cx + div][0] < p.x) cx += div;
+        if (bm[cy + div][1] < p.y) cy += div;
+        if (bm[cz + div][2] < p.z) cz += div;
+    }
+    cell[0] = cx; cell[1] = cy; cell[2] = cz;
+}
+
+// trianglelist.cpp:452-503: face-connected flood fill from the cell of vertex a.  `cells` receives the ids;
+// `bits` is a DIV^3-bit visited set, all-zero on entry and on exit.
+void fill_cube(const float (*bm)[4], std::vector<uint8_t> &bits, std::vector<uint32_t> &cells, F3 a, F3 b, F3 c)
+{
+    int cell[3];
+    box_address(bm, a, cell);
+    uint32_t id = (uint32_t)cell[0] + (uint32_t)cell[1] * DIV + (uint32_t)cell[2] * DIV * DIV;
+    cells.clear();
+    bits[id >> 3] |= (uint8_t)(1u << (id & 7));
+    cells.push_back(id);
+    for (size_t cur = 0; cur < cells.size(); ++cur) {
+        id = cells[cur];
+        cell[2] = (int)(id / (DIV * DIV));
+        cell[1] = (int)((id % (DIV * DIV)) / DIV);
+        cell[0] = (int)(id % DIV);
+        float lo[3], hi[3];
+        for (int i = 0; i < 3; ++i) { lo[i] = bm[cell[i]][i]; hi[i] = bm[cell[i] + 1][i]; }
+        for (int i = 0; i < 3; ++i) {
+            for (int j = -1; j <= 1; j += 2) {
+                cell[i] += j;
+                if (0 <= cell[i] && cell[i] < DIV) {
+                    uint32_t nid = (uint32_t)cell[0] + (uint32_t)cell[1] * DIV + (uint32_t)cell[2] * DIV * DIV;
+                    uint8_t mask = (uint8_t)(1u << (nid & 7));
+                    if (!(bits[nid >> 3] & mask)) {
+                        lo[i] = bm[cell[i]][i];
+                        hi[i] = bm[cell[i] + 1][i];
+                        if (box_hits_triangle(lo, hi, a, b, c)) {
+                            bits[nid >> 3] |= mask;
+                            cells.push_back(nid);
+                        }
+                    }
+                }
+                cell[i] -= j;
+            }
+            lo[i] = bm[cell[i]][i];
+            hi[i] = bm[cell[i] + 1][i];
+        }
+    }
+    for (uint32_t v : cells) bits[v >> 3] = 0; // clear only what was touched (a byte may be cleared repeatedly)
+}
+
+template <class T> T *alloc_n(uint64_t n) { return (T *)std::malloc((size_t)std::max<uint64_t>(1, n) * sizeof(T)); }
+
+} // namespace
+
+extern "C" {
+
+void rtHipFree(void *p) { std::free(p); }
+
+int rtHipBuildCameraList(cl_uint W, cl_uint H, const cl_float eye[4], const cl_float eyeToTopLeft[4],
+                         const cl_float leftToRight[4], const cl_float topToBottom[4], cl_float pixelSizeInv,
+                         cl_uint triangleCount, const cl_float3 *vertex, const cl_int3 *triIndex, int threads,
+                         cl_uint **outStart, cl_uint **outEnd, cl_uint **outList, uint64_t *outListSize)
+{
+    if (!outStart || !outEnd || !outList || !outListSize || W == 0 || H == 0) return -1;
+    const uint64_t P = (uint64_t)W * H;
+    Camera cam{ F3{ eye[0], eye[1], eye[2] }, F3{ eyeToTopLeft[0], eyeToTopLeft[1], eyeToTopLeft[2] },
+                F3{ leftToRight[0], leftToRight[1], leftToRight[2] }, F3{ topToBottom[0], topToBottom[1], topToBottom[2] },
+                pixelSizeInv };
+
+    // project once
+    std::vector<F2> pos((size_t)triangleCount * 3);
+    parallel_chunks(threads, triangleCount, [&](int, uint64_t lo, uint64_t hi) {
+        for (uint64_t t = lo; t < hi; ++t)
+            for (int k = 0; k < 3; ++k) pos[3 * t + k] = camera_position(cam, ld3(vertex[triIndex[t].s[k]]));
+    });
+
+    // pass 1: count per pixel
+    std::vector<std::atomic<uint32_t>> count(P);
+    for (auto &c : count) c.store(0, std::memory_order_relaxed);
+    parallel_chunks(threads, triangleCount, [&](int, uint64_t lo, uint64_t hi) {
+        for (uint64_t t = lo; t < hi; ++t)
+            fill_rectangle(W, H, pos[3 * t], pos[3 * t + 1], pos[3 * t + 2],
+                           [&](uint64_t px) { count[px].fetch_add(1, std::memory_order_relaxed); });
+    });
+    cl_uint *start = alloc_n<cl_uint>(P), *end = alloc_n<cl_uint>(P);
+    if (!start || !end) { std::free(start); std::free(end); return -2; }
+    uint64_t total = 0;
+    for (uint64_t p = 0; p < P; ++p) { start[p] = (cl_uint)total; total += count[p].load(std::memory_order_relaxed); end[p] = (cl_uint)total; }
+    if (total > 0xffffffffull) { std::free(start); std::free(end); return -3; }
+    cl_uint *list = alloc_n<cl_uint>(total);
+    if (!list) { std::free(start); std::free(end); return -2; }
+
+    // pass 2: fill (cursor = start + running count), then put each pixel's entries in ascending triangle order,
+    // which is the order the reference's sort on pixel*T+tri keys gives (:161,:565-574)
+    for (auto &c : count) c.store(0, std::memory_order_relaxed);
+    parallel_chunks(threads, triangleCount, [&](int, uint64_t lo, uint64_t hi) {
+        for (uint64_t t = lo; t < hi; ++t)
+            fill_rectangle(W, H, pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], [&](uint64_t px) {
+                list[start[px] + count[px].fetch_add(1, std::memory_order_relaxed)] = (cl_uint)t;
+            });
+    });
+    parallel_chunks(threads, P, [&](int, uint64_t lo, uint64_t hi) {
+        for (uint64_t p = lo; p < hi; ++p) std::sort(list + start[p], list + end[p]);
+    });
+
+    // neighbour de-duplication: a pixel whose list equals its left (else upper) neighbour's aliases it (:580-613)
+    uint64_t squeezed = 0;
+    for (uint64_t p = 0; p < P; ++p) {
+        const uint32_t x = (uint32_t)(p % W), y = (uint32_t)(p / W);
+        const cl_uint n = end[p] - start[p];
+        std::memmove(list + (start[p] - squeezed), list + start[p], (size_t)n * sizeof(cl_uint));
+        start[p] -= (cl_uint)squeezed;
+        end[p] -= (cl_uint)squeezed;
+        bool aliased = false;
+        if (0 < x && n == end[p - 1] - start[p - 1] && 0 == std::memcmp(list + start[p - 1], list + start[p], (size_t)n * sizeof(cl_uint))) {
+            squeezed += n; start[p] = start[p - 1]; end[p] = end[p - 1]; aliased = true;
+        }
+        if (0 < y && !aliased && n == end[p - W] - start[p - W] && 0 == std::memcmp(list + start[p - W], list + start[p], (size_t)n * sizeof(cl_uint))) {
+            squeezed += n; start[p] = start[p - W]; end[p] = end[p - W];
+        }
+    }
+    *outStart = start; *outEnd = end; *outList = list; *outListSize = total - squeezed;
+    return 0;
+}
+
+int rtHipBuildSceneGrid(cl_uint vertexCount, cl_uint triangleCount, const cl_float3 *vertex, const cl_int3 *triIndex,
+                        int threads, cl_float3 outBoxMin[257], cl_uint **outStart, cl_uint **outList, uint64_t *outListSize)
+{
+    if (!outBoxMin || !outStart || !outList || !outListSize) return -1;
+    static_assert(sizeof(cl_float3) == 16, "padded float3");
+    float (*bm)[4] = reinterpret_cast<float (*)[4]>(outBoxMin);
+    std::memset(bm, 0, sizeof(float) * 4 * (DIV + 1));
+
+    // split planes at vertex quantiles, midway between neighbours (:657-678); index arithmetic is 32-bit
+    // unsigned like the reference's (it wraps above 2^24 vertices -- kept)
+    if (0 < vertexCount) {
+        std::vector<float> val(vertexCount);
+        for (int w = 0; w < 3; ++w) {
+            for (cl_uint v = 0; v < vertexCount; ++v) val[v] = vertex[v].s[w];
+            std::sort(val.begin(), val.end());
+            for (int i = 0; i < DIV + 1; ++i) {
+                cl_uint index = ((cl_uint)i * (vertexCount - 1)) / DIV;
+                if (0 < index && index < vertexCount) bm[i][w] = (val[index] + val[index - 1]) / 2.f;
+                else bm[i][w] = val[index];
+            }
+        }
+    }
+
+    const uint64_t CELLS = (uint64_t)DIV * DIV * DIV;
+    const int nthreads = (int)std::min<uint64_t>((uint64_t)hw_threads(threads), std::max<uint64_t>(1, triangleCount));
+    // per-thread (cell, triangle) pairs; triangles are dealt in contiguous ranges so each thread's pairs are
+    // already ascending in triangle id
+    std::vector<std::vector<uint32_t>> cellOf(nthreads), triOf(nthreads);
+    parallel_chunks(nthreads, triangleCount, [&](int t, uint64_t lo, uint64_t hi) {
+        std::vector<uint8_t> bits(CELLS / 8, 0);
+        std::vector<uint32_t> cells;
+        for (uint64_t tri = lo; tri < hi; ++tri) {
+            const cl_int3 &vi = triIndex[tri];
+            fill_cube(bm, bits, cells, ld3(vertex[vi.s[0]]), ld3(vertex[vi.s[1]]), ld3(vertex[vi.s[2]]));
+            for (uint32_t c : cells) { cellOf[t].push_back(c); triOf[t].push_back((uint32_t)tri); }
+        }
+    });
+
+    cl_uint *start = alloc_n<cl_uint>(CELLS + 1);
+    if (!start) return -2;
+    std::memset(start, 0, (CELLS + 1) * sizeof(cl_uint));
+    uint64_t total = 0;
+    for (int t = 0; t < nthreads; ++t) { total += cellOf[t].size(); for (uint32_t c : cellOf[t]) ++start[c + 1]; }
+    if (total > 0xffffffffull) { std::free(start); return -3; }
+    for (uint64_t c = 1; c <= CELLS; ++c) start[c] += start[c - 1]; // :717-719
+    cl_uint *list = alloc_n<cl_uint>(total);
+    if (!list) { std::free(start); return -2; }
+    {
+        // threads hold ascending triangle ranges, so filling thread by thread keeps each cell's list ascending
+        std::vector<cl_uint> cursor(start, start + CELLS);
+        for (int t = 0; t < nthreads; ++t)
+            for (size_t k = 0; k < cellOf[t].size(); ++k) list[cursor[cellOf[t][k]]++] = triOf[t][k];
+    }
+    *outStart = start; *outList = list; *outListSize = total;
+    return 0;
+}
+
+} // extern "C"

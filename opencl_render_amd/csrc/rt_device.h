@@ -1,0 +1,58 @@
+// rt_device.h -- device-side scene description shared by the HIP kernels (rt_kernels.hip) and the host API
+// (rt_api.cpp).  Plain C++ POD, passed to kernels by value in the kernarg segment.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+
+#define RT_TILE 128            // tile edge (pixels); the reference's NDRange granule (raytrace.c:507)
+#define RT_TILE_PIXELS (RT_TILE * RT_TILE)
+#define RT_PATCH 16            // a 256-thread workgroup renders a 16x16 pixel patch; each wave an 8x8 quadrant
+#define RT_RING 12             // ray queue slots per pixel (raytrace_opencl.c:404)
+#define RT_GRID_DIV 256
+
+// Layout of the device-resident scene.
+//
+//  triRec   [T][16 floats]  pre-resolved intersection record, one 64-byte line per triangle:
+//                           a.xyz | ab.xyz | ac.xyz | n.xyz (= cross(ac,ab)) | abab abac acac 1/(abac^2-abab*acac)
+//                           Every field is the value the reference recomputes per test (raytrace_opencl.c:131-149),
+//                           produced once on the device with the same fp32 operations, so results are bit-identical
+//                           while a candidate test costs one 64-B gather instead of 16 B index + 3 x 16 B vertices.
+//  triShade [T][24 floats]  what only a shaded hit needs: b.xyz c.xyz | nA nB nC | uvA uvB uvC | materialId | pad
+//  boxMin   [3][257]        split planes, one array per axis (staged into LDS by every workgroup)
+//  camStart/camEnd          per pixel of this scene's tiles, TILE-MAJOR: index = slot*128*128 + ly*128 + lx
+//  tileBuf  [slot][3][128*128] u16 planes R,G,B
+struct RtDevScene {
+    // camera (raytrace.h:61-66)
+    float eye[3], topLeft[3], lr[3], tb[3];
+    float pixelSizeInv;
+    uint32_t width, height, sampleCount;
+    // tiles rendered by this scene instance
+    const uint32_t *tileIds;
+    uint32_t tileCount, tilesX;
+    const uint32_t *camStart, *camEnd, *camList;
+    // geometry
+    uint32_t triangleCount;
+    const float *triRec;
+    const float *triShade;
+    // grid
+    const float *boxMin;
+    const uint32_t *gridStart, *gridList;
+    // materials
+    uint32_t materialCount, texelCount;
+    const uint32_t *matSize; // 2 x 5 per material
+    const int32_t *matStart; // 5 per material
+    const uint8_t *textures; // 4 bytes per texel
+    const float *bumpSin, *bumpCos; // [256*256] host-libm tables, index (hE<<8)|h0 (see rt_api.cpp)
+    // lights
+    uint32_t lightCount;
+    const int32_t *lightType;
+    const float *lightPos, *lightDir, *lightCol; // 4 floats each
+    const float *lightRadius, *lightHalfAtt;
+    const float *lightSpread; // per light: (float)(sin((r/2)*PI_F/180) * sqrt(|dir|^2)), host libm (raytrace_opencl.c:594)
+    // outputs
+    uint16_t *tileBuf;
+    unsigned long long *stats; // 7 counters, only touched by the counted kernel variant
+};
+
+#endif

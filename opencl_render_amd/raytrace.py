@@ -1,0 +1,335 @@
+"""ctypes binding of libraytrace_hip.so (the C ABI in include/raytrace_hip.h).
+
+This is the stub a Python host would write against the library; it mirrors the reference's own interface for the
+hot path (``RaytraceAll`` and friends, reference ``source/opencl/raytrace.h:37-106``) name for name, and adds the
+resident layer (``rtHip*``).  There is no fallback: if the shared library is missing the import of this module's
+``lib()`` raises, and on a machine without a HIP device every computing call returns failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .scene import GRID_DIV, Scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraytrace_hip.so")
+TILE = 128
+
+
+class Float3(C.Structure):  # cl_float3 == cl_float4: 16 bytes, passed as two SSE eightbytes on SysV
+    _fields_ = [("s", C.c_float * 4)]
+
+
+class UInt2(C.Structure):
+    _fields_ = [("s", C.c_uint32 * 2)]
+
+
+class SceneDesc(C.Structure):  # rtHipSceneDesc
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("eye", C.c_float * 4), ("eyeToTopLeft", C.c_float * 4), ("leftToRight", C.c_float * 4), ("topToBottom", C.c_float * 4),
+        ("pixelSizeInv", C.c_float),
+        ("camStart", C.c_void_p), ("camEnd", C.c_void_p), ("camList", C.c_void_p),
+        ("camListSize", C.c_uint64),
+        ("sampleCount", C.c_uint32),
+        ("vertexCount", C.c_uint32), ("vertex", C.c_void_p),
+        ("triangleCount", C.c_uint32), ("triIndex", C.c_void_p), ("triMaterial", C.c_void_p), ("triUv", C.c_void_p), ("triNormal", C.c_void_p),
+        ("axesDiv", C.c_int32), ("boxMin", C.c_void_p), ("gridStart", C.c_void_p), ("gridList", C.c_void_p),
+        ("materialCount", C.c_uint32), ("matSize", C.c_void_p), ("matStart", C.c_void_p),
+        ("texturesSize", C.c_uint32), ("textures", C.c_void_p),
+        ("lightCount", C.c_uint32), ("lightType", C.c_void_p), ("lightPos", C.c_void_p), ("lightDir", C.c_void_p), ("lightCol", C.c_void_p),
+        ("lightRadius", C.c_void_p), ("lightHalfAtt", C.c_void_p),
+    ]
+
+
+class Stats(C.Structure):  # rtHipStats
+    _fields_ = [(n, C.c_uint64) for n in ("primarySamples", "primaryCandidates", "gridRays", "gridCells", "gridCandidates", "shadedHits", "texelFetches")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# Every symbol include/raytrace_hip.h declares, in declaration order (tests check the library exports them all).
+DROPIN_SYMBOLS = [
+    "RaytraceAll", "InitOpenCL", "ResetComputationType", "GetIsComputationTypeUpdated", "GetComputationTypeCount",
+    "GetComputationTypeName", "GetProgress", "SetProgress", "GetStartTime", "GetEndTime", "ResetTime",
+    "dot", "cross", "normalize", "vector", "bindf", "GetPointToLineSqLen", "RayIntersectsTriangle", "GetBoxAddress",
+]
+RESIDENT_SYMBOLS = [
+    "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles",
+    "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
+    "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildSceneGrid", "rtHipFree",
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libraytrace_hip.so (built by ``__graft_entry__.build()`` / ``make -C opencl_render_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+    L.RaytraceAll.restype = u32
+    L.RaytraceAll.argtypes = [u32, UInt2, Float3, Float3, Float3, Float3, f32, vp, vp, vp, C.c_ssize_t, u32, u32, vp, u32, vp, vp, vp, vp,
+                              i32, vp, vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.InitOpenCL.restype = None
+    L.ResetComputationType.restype = None
+    L.GetIsComputationTypeUpdated.restype = u32
+    L.GetComputationTypeCount.restype = C.c_size_t
+    L.GetComputationTypeName.restype = u32
+    L.GetComputationTypeName.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p]
+    L.GetProgress.restype = f32
+    L.SetProgress.argtypes = [f32]
+    L.GetStartTime.restype = C.c_long
+    L.GetEndTime.restype = C.c_long
+    L.dot.restype = f32
+    L.dot.argtypes = [Float3, Float3]
+    L.cross.restype = Float3
+    L.cross.argtypes = [Float3, Float3]
+    L.normalize.restype = Float3
+    L.normalize.argtypes = [Float3]
+    L.vector.restype = Float3
+    L.vector.argtypes = [Float3, Float3]
+    L.bindf.restype = f32
+    L.bindf.argtypes = [f32, f32, f32]
+    L.GetPointToLineSqLen.restype = f32
+    L.GetPointToLineSqLen.argtypes = [Float3, Float3, Float3]
+    L.RayIntersectsTriangle.restype = u32
+    L.RayIntersectsTriangle.argtypes = [Float3, Float3, f32, f32, Float3, Float3, Float3, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
+    L.GetBoxAddress.restype = type("Int3", (C.Structure,), {"_fields_": [("s", C.c_int32 * 4)]})
+    L.GetBoxAddress.argtypes = [i32, vp, Float3]
+
+    L.rtHipDeviceCount.restype = C.c_int
+    L.rtHipLastError.restype = C.c_char_p
+    L.rtHipSceneCreate.restype = vp
+    L.rtHipSceneCreate.argtypes = [C.c_int, C.POINTER(SceneDesc), vp, u32]
+    L.rtHipSceneDestroy.argtypes = [vp]
+    L.rtHipSceneDestroy.restype = None
+    L.rtHipSceneBytes.restype = u64
+    L.rtHipSceneBytes.argtypes = [vp]
+    L.rtHipRenderTiles.argtypes = [vp, vp]
+    L.rtHipRenderTilesCounted.argtypes = [vp, C.POINTER(Stats)]
+    L.rtHipTileBuffer.restype = vp
+    L.rtHipTileBuffer.argtypes = [vp]
+    L.rtHipTileBufferBytes.restype = u64
+    L.rtHipTileBufferBytes.argtypes = [vp]
+    L.rtHipDetile.argtypes = [C.c_int, vp, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.rtHipReadback.argtypes = [vp, vp, vp, vp]
+    L.rtHipSync.argtypes = [vp, vp]
+    L.rtHipKernelTime.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.rtHipBuildCameraList.argtypes = [u32, u32, vp, vp, vp, vp, f32, u32, vp, vp, C.c_int,
+                                       C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.rtHipBuildSceneGrid.argtypes = [u32, u32, vp, vp, C.c_int, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.rtHipFree.argtypes = [vp]
+    L.rtHipFree.restype = None
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().rtHipLastError().decode("utf-8", "replace")
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v) -> Float3:
+    out = Float3()
+    for i in range(3):
+        out.s[i] = float(v[i])
+    out.s[3] = 0.0
+    return out
+
+
+def _take(ptr: C.c_void_p, count: int, dtype) -> np.ndarray:
+    """Copies `count` items out of a malloc'ed block returned by a builder, then frees it."""
+    n = max(int(count), 0)
+    out = np.empty(n, dtype)
+    if n:
+        C.memmove(out.ctypes.data, ptr.value, n * out.itemsize)
+    lib().rtHipFree(ptr)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# builders (counterparts of CameraTriangleList::New / SceneTriangleList::New, trianglelist.cpp:520-626,655-737)
+# ---------------------------------------------------------------------------------------------------------------
+
+def build_camera_list(sc: Scene, threads: int = 0) -> None:
+    L = lib()
+    ps, pe, pl, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = L.rtHipBuildCameraList(sc.width, sc.height, _ptr(sc.eye), _ptr(sc.eye_to_top_left), _ptr(sc.left_to_right),
+                                _ptr(sc.top_to_bottom), sc.pixel_size_inv, sc.triangle_count, _ptr(sc.vertex), _ptr(sc.tri_index),
+                                threads, C.byref(ps), C.byref(pe), C.byref(pl), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"rtHipBuildCameraList failed ({rc})")
+    sc.cam_start = _take(ps, sc.pixels, np.uint32)
+    sc.cam_end = _take(pe, sc.pixels, np.uint32)
+    sc.cam_list = _take(pl, n.value, np.uint32)
+
+
+def build_scene_grid(sc: Scene, threads: int = 0) -> None:
+    L = lib()
+    box = np.zeros((GRID_DIV + 1, 4), np.float32)
+    ps, pl, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = L.rtHipBuildSceneGrid(sc.vertex_count, sc.triangle_count, _ptr(sc.vertex), _ptr(sc.tri_index), threads, _ptr(box),
+                               C.byref(ps), C.byref(pl), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"rtHipBuildSceneGrid failed ({rc})")
+    sc.box_min = box
+    sc.grid_start = _take(ps, GRID_DIV ** 3 + 1, np.uint32)
+    sc.grid_list = _take(pl, n.value, np.uint32)
+
+
+def build_lists(sc: Scene, threads: int = 0) -> Scene:
+    build_camera_list(sc, threads)
+    build_scene_grid(sc, threads)
+    return sc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# drop-in layer
+# ---------------------------------------------------------------------------------------------------------------
+
+def raytrace_all(computation_type: int, sc: Scene):
+    """RaytraceAll through the drop-in ABI.  Returns (ok, R, G, B) with [H,W] uint16 planes."""
+    L = lib()
+    r = np.zeros(sc.pixels, np.uint16)
+    g = np.zeros(sc.pixels, np.uint16)
+    b = np.zeros(sc.pixels, np.uint16)
+    dim = UInt2()
+    dim.s[0], dim.s[1] = sc.width, sc.height
+    ok = L.RaytraceAll(
+        computation_type, dim, _f3(sc.eye), _f3(sc.eye_to_top_left), _f3(sc.left_to_right), _f3(sc.top_to_bottom),
+        sc.pixel_size_inv, _ptr(sc.cam_start), _ptr(sc.cam_end), _ptr(sc.cam_list), len(sc.cam_list), sc.sample_count,
+        sc.vertex_count, _ptr(sc.vertex), sc.triangle_count, _ptr(sc.tri_index), _ptr(sc.tri_material), _ptr(sc.tri_uv),
+        _ptr(sc.tri_normal), GRID_DIV, _ptr(sc.box_min), _ptr(sc.grid_start), _ptr(sc.grid_list), sc.material_count,
+        _ptr(sc.mat_size), _ptr(sc.mat_start), len(sc.textures), _ptr(sc.textures), sc.light_count, _ptr(sc.light_type),
+        _ptr(sc.light_pos), _ptr(sc.light_dir), _ptr(sc.light_col), _ptr(sc.light_radius), _ptr(sc.light_half_att),
+        _ptr(r), _ptr(g), _ptr(b))
+    shape = (sc.height, sc.width)
+    return bool(ok), r.reshape(shape), g.reshape(shape), b.reshape(shape)
+
+
+def computation_type_names() -> list:
+    L = lib()
+    L.InitOpenCL()
+    names = []
+    buf = C.create_string_buffer(256)
+    for i in range(L.GetComputationTypeCount()):
+        if L.GetComputationTypeName(i, 255, buf):
+            names.append(buf.value.decode())
+    return names
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# resident layer
+# ---------------------------------------------------------------------------------------------------------------
+
+def scene_desc(sc: Scene) -> SceneDesc:
+    d = SceneDesc()
+    d.width, d.height = sc.width, sc.height
+    for i in range(4):
+        d.eye[i] = float(sc.eye[i]); d.eyeToTopLeft[i] = float(sc.eye_to_top_left[i])
+        d.leftToRight[i] = float(sc.left_to_right[i]); d.topToBottom[i] = float(sc.top_to_bottom[i])
+    d.pixelSizeInv = sc.pixel_size_inv
+    d.camStart, d.camEnd, d.camList = _ptr(sc.cam_start), _ptr(sc.cam_end), _ptr(sc.cam_list)
+    d.camListSize = len(sc.cam_list)
+    d.sampleCount = sc.sample_count
+    d.vertexCount, d.vertex = sc.vertex_count, _ptr(sc.vertex)
+    d.triangleCount = sc.triangle_count
+    d.triIndex, d.triMaterial, d.triUv, d.triNormal = _ptr(sc.tri_index), _ptr(sc.tri_material), _ptr(sc.tri_uv), _ptr(sc.tri_normal)
+    d.axesDiv = GRID_DIV
+    d.boxMin, d.gridStart, d.gridList = _ptr(sc.box_min), _ptr(sc.grid_start), _ptr(sc.grid_list)
+    d.materialCount, d.matSize, d.matStart = sc.material_count, _ptr(sc.mat_size), _ptr(sc.mat_start)
+    d.texturesSize, d.textures = len(sc.textures), _ptr(sc.textures)
+    d.lightCount, d.lightType = sc.light_count, _ptr(sc.light_type)
+    d.lightPos, d.lightDir, d.lightCol = _ptr(sc.light_pos), _ptr(sc.light_dir), _ptr(sc.light_col)
+    d.lightRadius, d.lightHalfAtt = _ptr(sc.light_radius), _ptr(sc.light_half_att)
+    return d
+
+
+def tile_count(width: int, height: int) -> int:
+    return ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+
+
+def tiles_of_rank(width: int, height: int, rank: int, world: int) -> np.ndarray:
+    """Round-robin deal of the 128x128 tiles."""
+    return np.arange(rank, tile_count(width, height), world, dtype=np.uint32)
+
+
+class ResidentScene:
+    """A scene resident in one GPU's HBM (rtHipScene)."""
+
+    def __init__(self, sc: Scene, device: int = 0, tiles: Optional[Sequence[int]] = None):
+        L = lib()
+        self.scene = sc
+        self.device = device
+        self.tiles = None if tiles is None else np.ascontiguousarray(tiles, np.uint32)
+        d = scene_desc(sc)
+        self.handle = L.rtHipSceneCreate(device, C.byref(d), _ptr(self.tiles), 0 if self.tiles is None else len(self.tiles))
+        if not self.handle:
+            raise RuntimeError("rtHipSceneCreate failed: " + last_error())
+        if self.tiles is None:
+            self.tiles = np.arange(tile_count(sc.width, sc.height), dtype=np.uint32)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rtHipSceneDestroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {last_error()}")
+
+    def render(self, stream: int = 0):
+        self._check(lib().rtHipRenderTiles(self.handle, stream or None), "rtHipRenderTiles")
+
+    def render_counted(self) -> dict:
+        st = Stats()
+        self._check(lib().rtHipRenderTilesCounted(self.handle, C.byref(st)), "rtHipRenderTilesCounted")
+        return st.as_dict()
+
+    def sync(self, stream: int = 0):
+        self._check(lib().rtHipSync(self.handle, stream or None), "rtHipSync")
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(lib().rtHipKernelTime(self.handle, C.byref(ms), C.byref(n)), "rtHipKernelTime")
+        return ms.value, n.value
+
+    def tile_buffer(self):
+        return lib().rtHipTileBuffer(self.handle), lib().rtHipTileBufferBytes(self.handle)
+
+    def bytes(self) -> int:
+        return lib().rtHipSceneBytes(self.handle)
+
+    def readback(self, planes=None):
+        sc = self.scene
+        if planes is None:
+            planes = [np.zeros(sc.pixels, np.uint16) for _ in range(3)]
+        self._check(lib().rtHipReadback(self.handle, _ptr(planes[0]), _ptr(planes[1]), _ptr(planes[2])), "rtHipReadback")
+        return planes
+
+
+def render_resident(sc: Scene, device: int = 0):
+    """Upload, render every tile once, read back: returns [H,W] uint16 R,G,B."""
+    rs = ResidentScene(sc, device)
+    try:
+        rs.render()
+        planes = rs.readback()
+    finally:
+        rs.close()
+    return [p.reshape(sc.height, sc.width) for p in planes]

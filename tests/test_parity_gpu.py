@@ -1,0 +1,156 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  * the golden fixtures minted from the reference kernel (bit-exact u16 planes),
+  * the CPU oracle on freshly seeded scenes and on sampled pixel rows of a full-size frame,
+  * size-independent properties at BASELINE sizes (tile-partition invariance, plane accumulation, determinism).
+Bar: bit-exact.  The only floating-point latitude the design has (double pow/exp2 on the device vs glibc pow,
+DESIGN.md) is exercised by `spot_finite_range` and still expected to match exactly on these fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import golden_names, load_golden_scene
+from opencl_render_amd import raytrace as R, scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(hip_lib):
+    if hip_lib.rtHipDeviceCount() < 1:
+        pytest.fail("no HIP device: the GPU parity tests cannot run (and the product has no CPU fallback)")
+
+
+def assert_planes(got, want, what):
+    for ch, g, w in zip("RGB", got, want):
+        g = np.asarray(g).reshape(np.asarray(w).shape)
+        bad = int((g != w).sum())
+        assert bad == 0, f"{what}: plane {ch} differs in {bad}/{g.size} pixels, max |d|={int(np.abs(g.astype(int) - w.astype(int)).max())}"
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_dropin_raytraceall_matches_golden(name):
+    sc, want = load_golden_scene(name)
+    ok, r, g, b = R.raytrace_all(1, sc)
+    assert ok, R.last_error()
+    assert_planes((r, g, b), want, name)
+
+
+@pytest.mark.parametrize("name", ["mixed_materials_textured", "mirror_hall", "odd_size_multi_tile"])
+def test_resident_layer_matches_golden_and_counts_work(name):
+    sc, want = load_golden_scene(name)
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        got = rs.readback()
+        assert_planes(got, want, name)
+        # the counted variant computes the same image and the same work counters as the oracle
+        stats = rs.render_counted()
+        got2 = rs.readback([np.zeros(sc.pixels, np.uint16) for _ in range(3)])
+        assert_planes(got2, want, name + " (counted)")
+        _, ostats = O.oracle_render(sc, threads=os.cpu_count() or 1, with_stats=True)
+        assert stats == ostats
+        ms, n = rs.kernel_time_ms()
+        assert n == 1 and ms > 0
+    finally:
+        rs.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_tile_partition_is_invisible(world):
+    """round-robin 128x128 tiles, each 'rank' renders only its slice of the camera lists; the sum of the
+    ranks' planes is the full frame (the RNG seed uses the global pixel id)."""
+    sc, want = load_golden_scene("odd_size_multi_tile")
+    planes = [np.zeros(sc.pixels, np.uint16) for _ in range(3)]
+    for rank in range(world):
+        tiles = R.tiles_of_rank(sc.width, sc.height, rank, world)
+        if len(tiles) == 0:
+            continue
+        rs = R.ResidentScene(sc, 0, tiles)
+        try:
+            rs.render()
+            rs.readback(planes)
+        finally:
+            rs.close()
+    assert_planes(planes, want, f"world={world}")
+
+
+def test_readback_accumulates_with_saturation():
+    sc, want = load_golden_scene("degenerate_and_outside")
+    planes = [np.full(sc.pixels, 60000, np.uint16) for _ in range(3)]
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        rs.readback(planes)
+    finally:
+        rs.close()
+    for p, w in zip(planes, want):
+        assert np.array_equal(p.reshape(w.shape), np.minimum(60000 + w.astype(np.int64), 65535).astype(np.uint16))
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_fresh_scenes_match_oracle(seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mats = [dict(color=rng.integers(0, 256, (6, 6, 3)), reflection=tuple(rng.integers(0, 160, 3)),
+                 transparency=tuple(rng.integers(0, 160, 3)), bump=rng.integers(0, 256, (8, 8, 3)),
+                 luminance=tuple(rng.integers(0, 40, 3))) for _ in range(4)]
+    lights = [dict(type=int(t), pos=tuple(rng.uniform(-1, 1, 3) + [0, 0, 2]), dir=tuple(rng.uniform(-1, 1, 3)),
+                   col=tuple(rng.uniform(0, 1, 3)), radius=float(rng.uniform(0, 1)), half_att=float(rng.choice([np.inf, 2.5])))
+              for t in rng.integers(0, 10, 4)]
+    sc = S.make_soup(300, 200, 6000, 0.15, seed=seed, samples=3, materials=mats, lights=lights, random_uv=True, smooth_normals=True)
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    got = R.render_resident(sc, 0)
+    assert_planes(got, want, f"fresh seed {seed}")
+
+
+def test_determinism_two_renders_identical():
+    sc, _ = load_golden_scene("mirror_hall")
+    a = R.render_resident(sc, 0)
+    b = R.render_resident(sc, 0)
+    assert_planes(a, b, "repeat")
+
+
+@pytest.fixture(scope="module")
+def full_size_scene():
+    """BASELINE config 2 geometry: 1920x1080, 100k-triangle soup (Lambert + one distant light here, so the grid path
+    runs too)."""
+    sc = S.make_soup(1920, 1080, 100_000, 0.01, seed=12345, samples=1)
+    R.build_lists(sc)
+    return sc
+
+
+def test_full_size_sampled_rows_match_oracle(full_size_scene):
+    sc = full_size_scene
+    got = R.render_resident(sc, 0)
+    rows = [0, 1, 269, 540, 811, 1079]
+    for y in rows:
+        want = O.oracle_render(sc, threads=os.cpu_count() or 1, first_pixel=y * sc.width, pixel_count=sc.width)
+        for ch, g, w in zip("RGB", got, want):
+            assert np.array_equal(g[y], w[y]), f"row {y} plane {ch}: {(g[y] != w[y]).sum()} pixels differ"
+    assert (got[0] > 0).mean() > 0.05
+
+
+def test_full_size_partition_and_primary_only_properties(full_size_scene):
+    sc = full_size_scene
+    full = R.render_resident(sc, 0)
+    planes = [np.zeros(sc.pixels, np.uint16) for _ in range(3)]
+    for rank in range(8):  # the 8-GPU deal, rehearsed on one device
+        rs = R.ResidentScene(sc, 0, R.tiles_of_rank(sc.width, sc.height, rank, 8))
+        try:
+            rs.render()
+            rs.readback(planes)
+        finally:
+            rs.close()
+    assert_planes(planes, full, "8-way tile deal at 1080p")
+    # primary-only material: out = luminance => every lit pixel is exactly 65535, rest 0
+    import copy
+    po = copy.copy(sc)
+    po.mat_size, po.mat_start, po.textures = S.pack_materials([S.primary_only_material(0)])
+    po.tri_material = np.zeros(sc.triangle_count, np.int32)
+    empty = S.pack_lights([])
+    po.light_type, po.light_pos, po.light_dir, po.light_col, po.light_radius, po.light_half_att = empty
+    r, g, b = R.render_resident(po, 0)
+    assert set(np.unique(r).tolist()) <= {0, 65535} and np.array_equal(r, g) and np.array_equal(g, b)
+    assert np.array_equal(r > 0, full[0] > 0)  # same jitter, same nearest hits: the lit mask is identical
