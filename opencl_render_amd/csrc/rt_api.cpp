@@ -153,6 +153,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 }
             }
         }
+        // a bad id would be an out-of-bounds gather on the device: check on the host, where it is a loop
+        for (uint64_t i = 0; i < d->camListSize; ++i)
+            if (d->camList[i] >= d->triangleCount) return fail("camera list entry %llu = %u is not a triangle (count %u)", (unsigned long long)i, d->camList[i], d->triangleCount);
         if (sc->upload(lstart.data(), lstart.size(), &D.camStart, "camStart")) return -1;
         if (sc->upload(lend.data(), lend.size(), &D.camEnd, "camEnd")) return -1;
         if (slice) { if (sc->upload(compact.data(), compact.size(), &D.camList, "camList")) return -1; }
@@ -200,6 +203,11 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
         if (!d->gridStart) return fail("null scenePixelTriangleListStart");
         const uint64_t listSize = d->gridStart[cells];
+        for (uint64_t c = 0; c < cells; ++c)
+            if (d->gridStart[c] > d->gridStart[c + 1]) return fail("scenePixelTriangleListStart is not monotone at cell %llu", (unsigned long long)c);
+        if (listSize && !d->gridList) return fail("null scenePixelTriangleList");
+        for (uint64_t i = 0; i < listSize; ++i)
+            if (d->gridList[i] >= d->triangleCount) return fail("grid list entry %llu = %u is not a triangle (count %u)", (unsigned long long)i, d->gridList[i], d->triangleCount);
         if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
         if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
         HIP_OK(hipStreamSynchronize(sc->stream));
