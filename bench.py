@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark (BASELINE.json: Mrays/s + ms/frame at 1920x1080, 1M-triangle scene).
+
+    python bench.py --gpus 1 --steps K --warmup W                       (default: N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: every rank renders its 128x128 tiles of the frame (one launch of the trace kernel over the
+scene resident in its HBM), the tile buffers are gathered to rank 0 (RCCL) and rank 0 scatters them into the three
+row-major u16 planes on its device.  Inputs are resident before the timed region; outputs stay on the device.
+The same frame is split over more GPUs as N grows => "scaling": "strong".
+
+Workloads (synthetic seeded triangle soups, lists built by the library's host builders):
+    lambert_1m   1920x1080, 1M triangles (edge 0.004), white Lambert + 1 distant light, S=1   <- default, BASELINE metric
+    primary_100k 1920x1080, 100k triangles (edge 0.01), luminance-only material, no lights (primary rays only)
+    lambert_4k   3840x2160, 1M triangles (edge 0.004), as lambert_1m
+One JSON line on stdout (rank 0); progress goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "lambert_1m": dict(width=1920, height=1080, triangles=1_000_000, edge=0.004, kind="lambert"),
+    "primary_100k": dict(width=1920, height=1080, triangles=100_000, edge=0.01, kind="primary"),
+    "lambert_4k": dict(width=3840, height=2160, triangles=1_000_000, edge=0.004, kind="lambert"),
+    "smoke": dict(width=256, height=256, triangles=10_000, edge=0.02, kind="lambert"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(stats: dict, lights: int) -> float:
+    """SURVEY.md section 8(d) gather-traffic model, no credit for cache reuse:
+    B = S*20*P + 68*candidates(primary) + sum over grid rays (8*cells + 68*candidates) + per shaded hit
+    (4 matId + 16 index + 48 normals + 48 vertices + 8 bump size) + per texel fetch (8 size + 4 start + 24 uv + 4 texel)
+    + boxMin (4112 B) and lights (60 B each) once per frame."""
+    return (20.0 * stats["primarySamples"] + 68.0 * stats["primaryCandidates"] + 8.0 * stats["gridCells"] + 68.0 * stats["gridCandidates"]
+            + 124.0 * stats["shadedHits"] + 40.0 * stats["texelFetches"] + 4112.0 + 60.0 * lights)
+
+
+def make_scene(name: str, samples: int):
+    from opencl_render_amd import raytrace as R, scene as S
+    w = WORKLOADS[name]
+    if w["kind"] == "primary":
+        sc = S.make_soup(w["width"], w["height"], w["triangles"], w["edge"], seed=12345, samples=samples,
+                         materials=[S.primary_only_material(256)], lights=[], random_uv=True, name=name)
+    else:
+        sc = S.make_soup(w["width"], w["height"], w["triangles"], w["edge"], seed=12345, samples=samples, name=name)
+    t0 = time.time()
+    R.build_camera_list(sc)
+    t1 = time.time()
+    R.build_scene_grid(sc)
+    t2 = time.time()
+    sc.meta.update(t_cam_list_s=t1 - t0, t_grid_s=t2 - t1)
+    return sc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="lambert_1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from opencl_render_amd import raytrace as R, tiles as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available() or R.lib().rtHipDeviceCount() < 1:
+        sys.exit("bench.py: no HIP device visible -- the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- scene: built once on rank 0, shipped to the other ranks over RCCL -----------------------------------------
+    sc = None
+    if rank == 0:
+        t0 = time.time()
+        sc = make_scene(args.workload, args.samples)
+        log(f"scene {sc.name}: {sc.width}x{sc.height}, T={sc.triangle_count}, cam list {len(sc.cam_list)} (mean K_p "
+            f"{sc.sum_candidates() / sc.pixels:.2f}), grid list {len(sc.grid_list)}; host prep {time.time() - t0:.1f}s "
+            f"(camera lists {sc.meta['t_cam_list_s']:.2f}s, grid {sc.meta['t_grid_s']:.2f}s)")
+    if world > 1:
+        sc = T.broadcast_scene(sc, rank, device)
+    W, H, P, S = sc.width, sc.height, sc.pixels, sc.sample_count
+
+    my_tiles = R.tiles_of_rank(W, H, rank, world)
+    t0 = time.time()
+    rs = R.ResidentScene(sc, local_rank, my_tiles)
+    t_upload = time.time() - t0
+    buf_ptr, buf_bytes = rs.tile_buffer()
+    tile_tensor = T.alias_device_bytes(buf_ptr, buf_bytes, device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    planes = ids_dev = None
+    if rank == 0:
+        planes = torch.zeros(3 * P * 2, dtype=torch.uint8, device=device)
+        ids_dev = [torch.from_numpy(R.tiles_of_rank(W, H, r, world).astype(np.int32)).to(device) for r in range(world)]
+    L = R.lib()
+
+    def frame():
+        rs.render(stream)
+        gathered = T.gather_tiles(tile_tensor, W, H, rank, world)
+        if rank == 0:
+            planes.zero_()
+            base = planes.data_ptr()
+            for r in range(world):
+                n = ids_dev[r].numel()
+                if n:
+                    rc = L.rtHipDetile(local_rank, gathered[r].data_ptr(), ids_dev[r].data_ptr(), n, W, H,
+                                       base, base + 2 * P, base + 4 * P, stream)
+                    if rc != 0:
+                        raise RuntimeError("rtHipDetile: " + R.last_error())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        frame()
+    torch.cuda.synchronize()
+    rs.kernel_time_ms()  # drop warm-up launches from the kernel-time average
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = rs.kernel_time_ms()
+
+    # ---- un-timed: work counters for the byte model (instrumented kernel variant), frame for the parity gate -------
+    stats = rs.render_counted()
+    frame()
+    torch.cuda.synchronize()
+    total_stats = dict(stats)
+    if world > 1:
+        keys = sorted(stats)
+        t = torch.tensor([stats[k] for k in keys], dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        total_stats = {k: int(v) for k, v in zip(keys, t.tolist())}
+
+    if rank == 0:
+        got = planes.cpu().numpy().view(np.uint16).reshape(3, H, W)
+        ms_per_step = 1e3 * elapsed / args.steps
+        primary_rays = float(P) * S
+        total_rays = primary_rays + total_stats["gridRays"]
+        b_local = algorithmic_bytes(stats, sc.light_count)  # this rank's launch: its tiles only
+        achieved = b_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary rays; each also traces its shadow/bounce rays) at ms/frame = ms_per_step",
+            "value": round(primary_rays * args.steps / elapsed / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {W}x{H}, {sc.triangle_count} random triangles (edge {sc.meta.get('edge')}), "
+                                   f"{'luminance-only, primary rays only' if WORKLOADS[args.workload]['kind'] == 'primary' else 'white Lambert + 1 distant light (shadow ray + 1 diffuse bounce)'}"
+                                   f", S={S}, seed 12345",
+                       "width": W, "height": H, "triangles": sc.triangle_count, "samples": S, "lights": sc.light_count,
+                       "parallelism": f"128x128 tiles round-robin over {world} GPU(s), RCCL gather to rank 0"},
+            "total_mrays_per_s": round(total_rays * args.steps / elapsed / 1e6, 3),
+            "rays_per_frame": {"primary": int(primary_rays), "grid": int(total_stats["gridRays"])},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "rt_trace_kernel<false>", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                         "algorithmic_bytes_per_launch": int(b_local)},
+            "work_counters": total_stats,
+            "t_upload_s": round(t_upload, 3),
+            "t_host_prep_s": {"camera_lists": round(sc.meta.get("t_cam_list_s", 0), 3), "grid": round(sc.meta.get("t_grid_s", 0), 3)},
+        }
+        # ---- CPU baseline + parity gate (rank 0, N=1 only): the oracle on a bounded sample of the same frame ------
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O  # checker only: never part of the measured path
+            rows = list(range(0, H, 4))  # every 4th row, single thread (the reference's C path is single-threaded)
+            t0 = time.perf_counter()
+            bad = 0
+            for y in rows:
+                want = O.oracle_render(sc, threads=1, first_pixel=y * W, pixel_count=W)
+                for c in range(3):
+                    bad += int((want[c][y] != got[c, y]).sum())
+            t_cpu = time.perf_counter() - t0
+            cores = os.cpu_count() or 1
+            t0 = time.perf_counter()
+            O.oracle_render(sc, threads=cores)
+            t_all = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(len(rows) * W * S / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                                   "sample": f"every 4th row of the same frame ({len(rows)} rows, {len(rows) * W * S} primary samples, {t_cpu:.1f}s)",
+                                   "all_cores": {"value": round(P * S / t_all / 1e6, 4), "cores": cores, "sample": f"whole frame, OpenMP, {t_all:.1f}s"}}
+            out["parity"] = {"rows_checked": len(rows), "mismatching_values": bad, "bar": "bit-exact u16 planes vs CPU oracle"}
+            if bad:
+                print(json.dumps(out))
+                sys.exit(f"bench.py: GPU frame differs from the oracle in {bad} values -- timing is void")
+        print(json.dumps(out), flush=True)
+
+    rs.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -199,8 +199,10 @@ void    *rtHipTileBuffer(rtHipScene *scene);
 uint64_t rtHipTileBufferBytes(const rtHipScene *scene);
 
 /* De-tiles `tileCount` tiles held in a device buffer laid out like rtHipTileBuffer into three row-major
- * width x height u16 DEVICE planes (saturating add into what is there).  Used by the gather root. */
-int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIds, cl_uint tileCount,
+ * width x height u16 DEVICE planes (saturating add into what is there).  Used by the gather root, once per
+ * source rank.  tileIdsDevice is a DEVICE array of row-major tile ids (ids >= the image's tile count are
+ * skipped).  Asynchronous on `stream` (a hipStream_t as void*, NULL = the default stream); no allocation. */
+int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIdsDevice, cl_uint tileCount,
                 cl_uint width, cl_uint height, void *planeR, void *planeG, void *planeB, void *stream);
 
 /* Blocks until the scene's work is done, then adds its tiles into three HOST planes (width*height u16 each). */

@@ -353,23 +353,14 @@ int rtHipRenderTilesCounted(rtHipScene *sc, rtHipStats *stats)
 void *rtHipTileBuffer(rtHipScene *sc) { return sc ? (void *)sc->dev.tileBuf : nullptr; }
 uint64_t rtHipTileBufferBytes(const rtHipScene *sc) { return sc ? (uint64_t)sc->tileIds.size() * 3 * RT_TILE_PIXELS * 2 : 0; }
 
-int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIds, cl_uint tileCount, cl_uint width, cl_uint height,
+int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIdsDevice, cl_uint tileCount, cl_uint width, cl_uint height,
                 void *planeR, void *planeG, void *planeB, void *stream)
 {
-    if (!tileBuffer || !tileIds || !planeR || !planeG || !planeB) return fail("null argument");
+    if (!tileBuffer || !tileIdsDevice || !planeR || !planeG || !planeB) return fail("null argument");
     if (width == 0 || height == 0) return fail("empty image");
     HIP_OK(hipSetDevice(device));
-    hipStream_t st = (hipStream_t)stream;
-    const uint32_t tilesX = (width + RT_TILE - 1) / RT_TILE, tilesY = (height + RT_TILE - 1) / RT_TILE;
-    for (cl_uint i = 0; i < tileCount; ++i)
-        if (tileIds[i] >= tilesX * tilesY) return fail("tile id %u out of range", tileIds[i]);
-    cl_uint *dIds = nullptr;
-    HIP_OK(hipMalloc((void **)&dIds, (size_t)(tileCount ? tileCount : 1) * 4));
-    hipError_t e = hipMemcpyAsync(dIds, tileIds, (size_t)tileCount * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = rtk_launch_detile(tileBuffer, dIds, tileCount, width, height, tilesX, planeR, planeG, planeB, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(dIds);
-    if (e != hipSuccess) return fail("detile failed: %s", hipGetErrorString(e));
+    const uint32_t tilesX = (width + RT_TILE - 1) / RT_TILE;
+    HIP_OK(rtk_launch_detile(tileBuffer, tileIdsDevice, tileCount, width, height, tilesX, planeR, planeG, planeB, (hipStream_t)stream));
     return 0;
 }
 

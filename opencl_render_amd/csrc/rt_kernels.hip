@@ -615,8 +615,7 @@ __global__ __launch_bounds__(256) void rt_prepare_triangles(uint32_t triangleCou
 }
 
 // De-tiles [slot][3][128*128] tile buffers into three row-major planes with a saturating add (the ABI accumulates
-// into the caller's planes, raytrace_opencl.c:729-740).  One thread per 8 consecutive pixels of a tile row:
-// 16-byte loads and stores.
+// into the caller's planes, raytrace_opencl.c:729-740).  One thread per 8 consecutive pixels of a tile row.
 __global__ __launch_bounds__(256) void rt_detile_kernel(const uint16_t *__restrict__ tileBuf, const uint32_t *__restrict__ tileIds,
                                                         uint32_t tileCount, uint32_t width, uint32_t height, uint32_t tilesX,
                                                         uint16_t *planeR, uint16_t *planeG, uint16_t *planeB)
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(256) void rt_detile_kernel(const uint16_t *__restri
     const uint32_t plane = (gid / (segs * RT_TILE)) % 3;
     const uint32_t slot = gid / (segs * RT_TILE * 3);
     const uint32_t tile = tileIds[slot];
-    const uint32_t gy = (tile / tilesX) * RT_TILE + row;
+    const uint32_t gy = (tile / tilesX) * RT_TILE + row; // ids beyond the image fall out at the height test
     const uint32_t gx0 = (tile % tilesX) * RT_TILE + seg * 8;
     if (gy >= height || gx0 >= width) return;
     const uint16_t *src = tileBuf + ((size_t)slot * 3 + plane) * RT_TILE_PIXELS + row * RT_TILE + seg * 8;
