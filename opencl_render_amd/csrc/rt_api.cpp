@@ -210,6 +210,16 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             if (d->gridList[i] >= d->triangleCount) return fail("grid list entry %llu = %u is not a triangle (count %u)", (unsigned long long)i, d->gridList[i], d->triangleCount);
         if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
         if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
+        std::vector<unsigned long long> bits((size_t)(RT_GRID_DIV / 4) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4), 0ull);
+        for (uint32_t z = 0; z < RT_GRID_DIV; ++z)
+            for (uint32_t y = 0; y < RT_GRID_DIV; ++y) {
+                const uint64_t row = (uint64_t)y * RT_GRID_DIV + (uint64_t)z * RT_GRID_DIV * RT_GRID_DIV;
+                unsigned long long *w = bits.data() + ((y >> 2) * (RT_GRID_DIV / 4)) + (size_t)(z >> 2) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4);
+                const uint32_t shift = ((y & 3) << 2) | ((z & 3) << 4);
+                for (uint32_t x = 0; x < RT_GRID_DIV; ++x)
+                    if (d->gridStart[row + x] != d->gridStart[row + x + 1]) w[x >> 2] |= 1ull << (shift | (x & 3));
+            }
+        if (sc->upload(bits.data(), bits.size(), &D.gridBits, "gridBits")) return -1;
         HIP_OK(hipStreamSynchronize(sc->stream));
     }
 

@@ -38,6 +38,10 @@ struct RtDevScene {
     // grid
     const float *boxMin;
     const uint32_t *gridStart, *gridList;
+    // occupancy of the grid, one 64-bit word per 4x4x4 block of cells (2 MiB: L2-resident): word (cx>>2) + 64*(cy>>2)
+    // + 4096*(cz>>2), bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 set iff the cell's list is non-empty.  Lets the DDA walk
+    // empty space without touching the 67 MB gridStart array; empty cells have no effect on the result.
+    const unsigned long long *gridBits;
     // materials
     uint32_t materialCount, texelCount;
     const uint32_t *matSize; // 2 x 5 per material

@@ -192,17 +192,23 @@ __device__ uint32_t grid_trace(const RtDevScene &S, const Shared &sh, V3 o, V3 d
     float dy = (sh.planes[1][cy + py] - o.y) / d.y;
     float dz = (sh.planes[2][cz + pz] - o.z) / d.z;
     if (COUNT) cn.v[ST_GRAYS]++;
+    // occupancy word of the 4x4x4 block the walk is in; reloaded only when the walk leaves the block
+    uint32_t wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+    unsigned long long word = S.gridBits[wordAt];
     for (;;) {
-        const uint32_t id = (uint32_t)(cx + RT_GRID_DIV * cy + RT_GRID_DIV * RT_GRID_DIV * cz);
-        const uint32_t first = S.gridStart[id], last = S.gridStart[id + 1];
         float tbest = tmax; // reset per cell (:366)
-        if (COUNT) { cn.v[ST_GCELLS]++; cn.v[ST_GCAND] += last - first; }
-        for (uint32_t i = first; i < last; ++i) {
-            const uint32_t tri = S.gridList[i];
-            if (excluded != tri) {
-                float t, l1, l2;
-                if (tri_test(S.triRec, tri, o, d, tmin, tbest, t, l1, l2)) {
-                    best = tri; tbest = t; l1_out = l1; l2_out = l2;
+        if (COUNT) cn.v[ST_GCELLS]++;
+        if ((word >> ((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4))) & 1ull) {
+            const uint32_t id = (uint32_t)(cx + RT_GRID_DIV * cy + RT_GRID_DIV * RT_GRID_DIV * cz);
+            const uint32_t first = S.gridStart[id], last = S.gridStart[id + 1];
+            if (COUNT) cn.v[ST_GCAND] += last - first;
+            for (uint32_t i = first; i < last; ++i) {
+                const uint32_t tri = S.gridList[i];
+                if (excluded != tri) {
+                    float t, l1, l2;
+                    if (tri_test(S.triRec, tri, o, d, tmin, tbest, t, l1, l2)) {
+                        best = tri; tbest = t; l1_out = l1; l2_out = l2;
+                    }
                 }
             }
         }
@@ -222,6 +228,8 @@ __device__ uint32_t grid_trace(const RtDevScene &S, const Shared &sh, V3 o, V3 d
             if (cz < 0 || RT_GRID_DIV <= cz) break;
             dz = (sh.planes[2][cz + pz] - o.z) / d.z;
         }
+        const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+        if (at != wordAt) { wordAt = at; word = S.gridBits[at]; }
     }
     return best;
 }
@@ -537,7 +545,10 @@ __device__ V3 trace_sample(const RtDevScene &S, const Shared &sh, uint32_t pixel
 
 // Trace: grid = tileCount * 64 workgroups of 256 threads; workgroup = 16x16 patch, wave = 8x8 quadrant.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void rt_trace_kernel(const RtDevScene S)
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 5
+#endif
+__global__ __launch_bounds__(256, RT_TRACE_WAVES) void rt_trace_kernel(const RtDevScene S)
 {
     __shared__ Shared sh;
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) (&sh.planes[0][0])[i] = S.boxMin[i];

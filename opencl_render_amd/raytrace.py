@@ -16,7 +16,8 @@ import numpy as np
 from .scene import GRID_DIV, Scene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytrace_hip.so")
+# RT_HIP_LIB selects another build of the same library (kernel A/B experiments); default is the in-tree build.
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "libraytrace_hip.so")
 TILE = 128
 
 

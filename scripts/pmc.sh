@@ -1,0 +1,14 @@
+# usage: bash scripts/pmc.sh <tag> [workload]  -- separate rocprofv3 --pmc passes (no tracing domains mixed in)
+set -e
+tag=$1; wl=${2:-lambert_1m}
+export TMPDIR=/tmp
+out=gpurun_out/pmc_$tag
+mkdir -p $out
+run() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $out/$name.log 2>&1; }
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY
+run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run tcc TCC_HIT_sum TCC_MISS_sum
+python3 scripts/pmc_summary.py $out > $out/summary.txt
+cat $out/summary.txt
