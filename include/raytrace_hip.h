@@ -191,6 +191,20 @@ uint64_t rtHipSceneBytes(const rtHipScene *scene);
  * (a hipStream_t passed as void*; NULL = the scene's own stream).  Returns 0 on success. */
 int rtHipRenderTiles(rtHipScene *scene, void *stream);
 
+/* Two implementations of the same frame (identical planes):
+ *   WAVEFRONT (default) staged pipeline: primary -> rounds of (per-path logic, persistent grid trace with lane refill)
+ *                       -> ordered accumulate.  rtHipRenderTiles blocks until the frame's rounds have been issued.
+ *   MEGAKERNEL          one launch, one thread per pixel (kept for A/B runs and for the work counters). */
+#define RT_HIP_PIPELINE_MEGAKERNEL 0
+#define RT_HIP_PIPELINE_WAVEFRONT  1
+int rtHipSetPipeline(rtHipScene *scene, int pipeline);
+
+/* Per-stage device time: enable, render frames, then read the SUM over those frames in milliseconds for
+ * [0] primary, [1] logic, [2] grid trace, [3] accumulate (HIP events on the launch stream; adds two event records per
+ * launch, so leave it off in timed whole-frame runs).  *rounds = logic/trace rounds of the last frame. */
+int rtHipStageTiming(rtHipScene *scene, int enable);
+int rtHipStageTimes(rtHipScene *scene, double ms[4], uint64_t *rounds);
+
 /* Same, with work counters (slower; never used inside a timed region).  Synchronous. */
 int rtHipRenderTilesCounted(rtHipScene *scene, rtHipStats *stats);
 
@@ -211,8 +225,8 @@ int rtHipReadback(rtHipScene *scene, cl_ushort *outR, cl_ushort *outG, cl_ushort
 /* Waits for `stream` (NULL = scene stream). */
 int rtHipSync(rtHipScene *scene, void *stream);
 
-/* Average duration in milliseconds of the trace kernel over the launches recorded since the last call
- * (HIP events on the launch stream), and the number of launches.  Returns 0 on success. */
+/* Average device time in milliseconds of one rtHipRenderTiles frame (all its kernels) over the frames recorded since
+ * the last call (HIP events on the launch stream), and the number of frames.  Returns 0 on success. */
 int rtHipKernelTime(rtHipScene *scene, double *avgMs, uint64_t *launches);
 
 /* ------------------------------------------------------------------------------------------------------------

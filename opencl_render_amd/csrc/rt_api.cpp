@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -26,6 +27,11 @@ extern "C" hipError_t rtk_launch_prepare(uint32_t triangleCount, const void *ver
                                          const void *triUv, const void *triNormal, float *triRec, float *triShade, hipStream_t stream);
 extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
                                         uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream);
+
+extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
+extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
 
 namespace {
 
@@ -61,6 +67,17 @@ struct rtHipScene {
     // kernel timing: one event pair per launch since the last rtHipKernelTime
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t eventsUsed = 0;
+    // wavefront pipeline (rt_wavefront.hip)
+    int pipeline = RT_HIP_PIPELINE_WAVEFRONT;
+    RtWavefront wf{};
+    uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
+    uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
+    // per-stage device time of the frames since the last query: [primary, logic, trace, accum]
+    struct StageEvent { int stage; hipEvent_t a, b; };
+    std::vector<StageEvent> stageEvents;
+    size_t stageEventsUsed = 0;
+    bool stageTiming = false;
+    uint64_t roundsLast = 0;
 
     template <class T> int upload(const T *src, uint64_t count, const T **dst, const char *what)
     {
@@ -283,6 +300,94 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         D.stats = st;
         HIP_OK(hipStreamSynchronize(sc->stream));
     }
+
+    // --- wavefront pipeline buffers: worst case every pixel of every sample in a batch becomes a path ------------
+    {
+        if (d->lightCount >= 65536u) return fail("lightCount %u too large", d->lightCount);
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, sc->device));
+        const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
+        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16;
+        const uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
+        uint64_t sb = budget / (perPath * (pix ? pix : 1));
+        if (sb < 1) sb = 1;
+        if (sb > d->sampleCount) sb = d->sampleCount;
+        if (pix * sb > 0xfffffff0ull) return fail("tile set too large for one batch");
+        sc->samplesPerBatch = (uint32_t)sb;
+        const uint64_t cap = pix * sb;
+        RtWavefront &Wf = sc->wf;
+        Wf.capacity = (uint32_t)cap;
+        Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
+        if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
+            sc->alloc<float4>(cap, &Wf.cur0) || sc->alloc<float4>(cap, &Wf.cur1) || sc->alloc<float4>(cap, &Wf.cur2) ||
+            sc->alloc<float4>(cap, &Wf.shN) || sc->alloc<float4>(cap, &Wf.shWhere) || sc->alloc<float4>(cap, &Wf.shF0) ||
+            sc->alloc<float4>(cap, &Wf.shF1) || sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(cap, &Wf.shToL) ||
+            sc->alloc<float4>(cap, &Wf.shTex) || sc->alloc<float4>(cap, &Wf.shTransp) || sc->alloc<float4>(cap, &Wf.shRefl) ||
+            sc->alloc<float4>(cap, &Wf.shLum) || sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) ||
+            sc->alloc<float4>(cap, &Wf.reqO[0]) || sc->alloc<float4>(cap, &Wf.reqO[1]) || sc->alloc<float4>(cap, &Wf.reqD[0]) ||
+            sc->alloc<float4>(cap, &Wf.reqD[1]) || sc->alloc<uint2>(cap, &Wf.reqX[0]) || sc->alloc<uint2>(cap, &Wf.reqX[1]) ||
+            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(cap, &Wf.sampleOut) ||
+            sc->alloc<uint32_t>(2 * (RT_WF_MAX_ROUNDS + 2), &Wf.counts))
+            return -1;
+        Wf.cursors = Wf.counts + (RT_WF_MAX_ROUNDS + 2);
+        HIP_OK(hipHostMalloc((void **)&sc->hostCount, 64, hipHostMallocDefault));
+        const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+        sc->traceBlocks = cus * 8;                      // 8 waves/SIMD x 4 SIMDs = 8 four-wave workgroups per CU, all resident
+        sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
+        if (sc->logicBlocks == 0) sc->logicBlocks = 1;
+        const char *env = getenv("RT_HIP_PIPELINE");
+        if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
+    }
+    return 0;
+}
+
+// One frame through the staged pipeline: per sample batch -- primary, then rounds of (logic, trace) until no path is
+// waiting for the grid, then the ordered accumulate.  The round count is data dependent, so the queue length is read
+// back after every chunk of rounds (one small pinned copy + stream sync per chunk).
+int render_wavefront(rtHipScene *sc, hipStream_t st)
+{
+    const RtDevScene &D = sc->dev;
+    RtWavefront &Wf = sc->wf;
+    auto stage = [&](int which, auto &&launch) -> hipError_t {
+        if (!sc->stageTiming) return launch();
+        if (sc->stageEventsUsed == sc->stageEvents.size()) {
+            rtHipScene::StageEvent e{};
+            hipError_t er = hipEventCreate(&e.a);
+            if (er != hipSuccess) return er;
+            er = hipEventCreate(&e.b);
+            if (er != hipSuccess) return er;
+            sc->stageEvents.push_back(e);
+        }
+        rtHipScene::StageEvent &e = sc->stageEvents[sc->stageEventsUsed++];
+        e.stage = which;
+        hipError_t er = hipEventRecord(e.a, st);
+        if (er != hipSuccess) return er;
+        er = launch();
+        if (er != hipSuccess) return er;
+        return hipEventRecord(e.b, st);
+    };
+    uint64_t rounds = 0;
+    for (uint32_t base = 0; base < D.sampleCount; base += sc->samplesPerBatch) {
+        Wf.sampleBase = base;
+        Wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, D.sampleCount - base);
+        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * 2 * (RT_WF_MAX_ROUNDS + 2), st));
+        HIP_OK(stage(0, [&] { return rtw_launch_primary(&D, &Wf, st); }));
+        uint32_t r = 0;
+        for (;;) {
+            const uint32_t chunk = 4;
+            for (uint32_t k = 0; k < chunk && r < RT_WF_MAX_ROUNDS; ++k, ++r) {
+                HIP_OK(stage(1, [&] { return rtw_launch_logic(&D, &Wf, r, sc->logicBlocks, st); }));
+                HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, sc->traceBlocks, st); }));
+            }
+            HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + r, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            if (*sc->hostCount == 0) break;
+            if (r >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
+        }
+        rounds += r;
+        HIP_OK(stage(3, [&] { return rtw_launch_accum(&D, &Wf, base == 0 ? 1 : 0, st); }));
+    }
+    sc->roundsLast = rounds;
     return 0;
 }
 
@@ -322,6 +427,8 @@ void rtHipSceneDestroy(rtHipScene *sc)
     if (sc->device >= 0) (void)hipSetDevice(sc->device);
     if (sc->stream) (void)hipStreamSynchronize(sc->stream);
     for (auto &e : sc->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : sc->stageEvents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (sc->hostCount) (void)hipHostFree(sc->hostCount);
     for (void *p : sc->allocs) (void)hipFree(p);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
@@ -341,8 +448,44 @@ int rtHipRenderTiles(rtHipScene *sc, void *stream)
     }
     auto &ev = sc->events[sc->eventsUsed++];
     HIP_OK(hipEventRecord(ev.first, st));
-    HIP_OK(rtk_launch_trace(&sc->dev, 0, st));
+    if (sc->pipeline == RT_HIP_PIPELINE_WAVEFRONT) {
+        if (render_wavefront(sc, st) != 0) return -1;
+    } else {
+        HIP_OK(rtk_launch_trace(&sc->dev, 0, st));
+    }
     HIP_OK(hipEventRecord(ev.second, st));
+    return 0;
+}
+
+int rtHipSetPipeline(rtHipScene *sc, int pipeline)
+{
+    if (!sc) return fail("null scene");
+    if (pipeline != RT_HIP_PIPELINE_MEGAKERNEL && pipeline != RT_HIP_PIPELINE_WAVEFRONT) return fail("unknown pipeline %d", pipeline);
+    sc->pipeline = pipeline;
+    return 0;
+}
+
+int rtHipStageTiming(rtHipScene *sc, int enable)
+{
+    if (!sc) return fail("null scene");
+    sc->stageTiming = enable != 0;
+    sc->stageEventsUsed = 0;
+    return 0;
+}
+
+int rtHipStageTimes(rtHipScene *sc, double ms[4], uint64_t *rounds)
+{
+    if (!sc || !ms) return fail("null argument");
+    HIP_OK(hipSetDevice(sc->device));
+    for (int i = 0; i < 4; ++i) ms[i] = 0.0;
+    for (size_t i = 0; i < sc->stageEventsUsed; ++i) {
+        HIP_OK(hipEventSynchronize(sc->stageEvents[i].b));
+        float t = 0.f;
+        HIP_OK(hipEventElapsedTime(&t, sc->stageEvents[i].a, sc->stageEvents[i].b));
+        ms[sc->stageEvents[i].stage] += t;
+    }
+    sc->stageEventsUsed = 0;
+    if (rounds) *rounds = sc->roundsLast;
     return 0;
 }
 

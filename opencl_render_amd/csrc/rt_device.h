@@ -4,6 +4,7 @@
 #define RT_DEVICE_H
 
 #include <stdint.h>
+#include <hip/hip_vector_types.h> // float4 / uint4 / uint2 for the host-side view of the device structs
 
 #define RT_TILE 128            // tile edge (pixels); the reference's NDRange granule (raytrace.c:507)
 #define RT_TILE_PIXELS (RT_TILE * RT_TILE)
@@ -57,6 +58,34 @@ struct RtDevScene {
     // outputs
     uint16_t *tileBuf;
     unsigned long long *stats; // 7 counters, only touched by the counted kernel variant
+};
+
+// ---- wavefront pipeline buffers (rt_wavefront.hip) -------------------------------------------------------------------
+// A "path" is one sample of one pixel whose primary ray hit something; it gets a dense id `a` (allocated by the
+// primary stage) and lives in HBM between stages as structure-of-arrays state.  Rays that need the grid are appended
+// to a request queue; a persistent trace kernel consumes the queue with every lane busy (idle lanes refill from it).
+//   round r:   logic(r)  reads  req[r&1].path + res[q]   for q < counts[r]      -> appends to req[(r+1)&1], counts[r+1]
+//              trace(r+1) reads req[(r+1)&1][q]           for q < counts[r+1]    -> writes res[q]
+#define RT_WF_MAX_ROUNDS 4094
+struct RtWavefront {
+    uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
+    uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
+    uint32_t samplesInBatch;
+    // per-path state, indexed by path id
+    unsigned long long *rng; // generator state (raytrace_opencl.c:474-481)
+    uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel  z: head | tail<<4 | stage<<8 | light<<16  w: hit triangle
+    float4 *outc;            // accumulated colour xyz, w: hit distance
+    float4 *cur0, *cur1, *cur2; // ray in flight: o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera
+    float4 *shN, *shWhere, *shF0, *shF1, *shAtt, *shToL; // n.xyz,l1 | where.xyz,l2 | face0.xyz,lmin | face1.xyz,lmax | atten | toLight
+    float4 *shTex, *shTransp, *shRefl, *shLum;           // the hit's channel texels
+    float4 *ring;            // [capacity][12][3] queued rays, same packing as cur0..2
+    // ray requests / results
+    float4 *reqO[2], *reqD[2]; // o.xyz,tmin | d.xyz,tmax
+    uint2 *reqX[2];            // excluded triangle, path id
+    uint4 *res;                // hit triangle (0xffffffff = none), t, l1, l2 (float bits)
+    uint32_t *counts;          // [RT_WF_MAX_ROUNDS+2] queue length per round (zeroed per batch)
+    uint32_t *cursors;         // [RT_WF_MAX_ROUNDS+2] trace-kernel fetch cursor per round
+    float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 
 #endif

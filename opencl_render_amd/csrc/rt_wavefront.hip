@@ -1,0 +1,552 @@
+// rt_wavefront.hip -- the hot path as a staged wavefront pipeline for gfx950 (MI355X).
+//
+// Why: in a one-thread-per-pixel kernel only the pixels whose primary ray hit something (28 % in the headline scene)
+// do any secondary work, and their grid walks differ in length by 10x, so a wave averages 4-5 busy lanes of 64
+// (rocprofv3 PMC, profiles/r01_v1_*).  Here every ray that needs the grid becomes a queue entry, and a persistent
+// trace kernel walks the grid with all 64 lanes busy: a lane that finishes its ray pulls the next one.
+//
+//   wf_primary  one thread per (pixel, sample): jittered camera ray + per-pixel candidate list (raytrace_opencl.c:470-528).
+//               Hits become PATHS: dense id from a wave-aggregated atomic, state written to HBM (rt_device.h).
+//   wf_logic    one thread per live path: resumes the per-sample state machine of raytrace_opencl.c:532-724 where it
+//               stopped, runs it until the next grid ray (shadow ray :611, or a queued ray :530) and appends that ray
+//               to the next round's queue; paths with an empty ring retire their colour.
+//   wf_trace    persistent waves; each lane owns one queued ray and walks the non-uniform grid (:324-401) one cell per
+//               iteration; finished lanes refill from the queue (ballot + one atomic per wave).
+//   wf_accum    per pixel, samples in order: truncated saturating u16 accumulate into the tile buffer (:726-741).
+//
+// Per path everything happens in the reference's order (RNG draws, ring FIFO, light loop), and paths never interact,
+// so the planes are bit-identical to the single-launch kernel (rt_kernels.hip) and to the oracle.
+#include "rt_devfuncs.h"
+
+namespace {
+
+enum { WS_RAY = 0, WS_SHADOW = 1 };
+
+__device__ __forceinline__ float4 pack4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+// Wave-aggregated queue append: one atomic per wave for all lanes that `want` a slot.  Must be reached by the lanes
+// together (it ballots over the lanes that execute it).
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return 0;
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Nearest hit among the pixel's candidate list (raytrace_opencl.c:514-528): running maximum, ties keep the earliest.
+__device__ __forceinline__ uint32_t camera_scan(const RtDevScene &S, uint32_t localPixel, V3 o, V3 d, float tmin, float tmax,
+                                                uint32_t excluded, float &hit_t, float &hit_l1, float &hit_l2)
+{
+    uint32_t hit_tri = RT_NONE;
+    hit_t = tmax;
+    const uint32_t first = S.camStart[localPixel], last = S.camEnd[localPixel];
+    for (uint32_t i = first; i < last; ++i) {
+        const uint32_t tri = S.camList[i];
+        if (excluded != tri) {
+            float t, l1, l2;
+            if (tri_test(S.triRec, tri, o, d, tmin, hit_t, t, l1, l2)) {
+                hit_t = t; hit_tri = tri; hit_l1 = l1; hit_l2 = l2;
+            }
+        }
+    }
+    return hit_tri;
+}
+
+} // namespace
+
+// ---- stage 1: primary rays ---------------------------------------------------------------------------------------
+// grid = (tileCount*64, samplesInBatch); workgroup = 16x16 pixel patch, wave = 8x8 quadrant.
+__global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, const RtWavefront W)
+{
+    const uint32_t slot = blockIdx.x >> 6, patch = blockIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lx = (patch & 7) * RT_PATCH + (wave & 1) * 8 + (lane & 7);
+    const uint32_t ly = (patch >> 3) * RT_PATCH + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t tile = S.tileIds[slot];
+    const uint32_t gx = (tile % S.tilesX) * RT_TILE + lx;
+    const uint32_t gy = (tile / S.tilesX) * RT_TILE + ly;
+    const uint32_t sb = blockIdx.y;
+    const bool valid = gx < S.width && gy < S.height;
+
+    uint32_t hit_tri = RT_NONE;
+    float hit_t = 0.f, hit_l1 = 0.f, hit_l2 = 0.f;
+    uint64_t rng = 0;
+    V3 dir = mk(0.f, 0.f, 0.f);
+    const uint32_t localPixel = slot * RT_TILE_PIXELS + ly * RT_TILE + lx;
+    const uint32_t outSlot = localPixel * W.samplesInBatch + sb;
+    if (valid) {
+        const uint32_t pixel = gy * S.width + gx;
+        rng = (uint64_t)pixel * (uint64_t)S.sampleCount + (uint64_t)(W.sampleBase + sb + 1); // :481
+        const V3 lr = ld3(S.lr), tb = ld3(S.tb);
+        dir = ld3(S.topLeft);
+        float k = (float)gx + rand01(rng); // LR jitter first, then TB (:496-503)
+        dir.x += lr.x * k; dir.y += lr.y * k; dir.z += lr.z * k;
+        k = (float)gy + rand01(rng);
+        dir.x += tb.x * k; dir.y += tb.y * k; dir.z += tb.z * k;
+        hit_tri = camera_scan(S, localPixel, ld3(S.eye), dir, 0.f, RT_INF, RT_NONE, hit_t, hit_l1, hit_l2);
+        if (hit_tri == RT_NONE) W.sampleOut[outSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool born = valid && hit_tri != RT_NONE;
+    const uint32_t a = wave_append(&W.counts[0], born);
+    if (born) {
+        W.rng[a] = rng;
+        W.meta[a] = make_uint4(outSlot, localPixel, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), hit_tri);
+        W.outc[a] = make_float4(0.f, 0.f, 0.f, hit_t);
+        W.cur0[a] = pack4(ld3(S.eye), 0.f);
+        W.cur1[a] = pack4(dir, __uint_as_float(RT_NONE));
+        W.cur2[a] = make_float4(1.f, 1.f, 1.f, __uint_as_float((12u << 1) | 1u)); // maxBounces 12, fromCamera (:492,:505)
+        W.reqX[0][a] = make_uint2(RT_NONE, a);
+        W.res[a] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
+    }
+}
+
+// ---- stage 2: per-path state machine ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+{
+    __shared__ Shared sh; // only the texel/255 table is used here
+    sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
+    __syncthreads();
+
+    const uint32_t total = W.counts[round];
+    const uint32_t in = round & 1, outq = in ^ 1;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t waveId = (blockIdx.x * 256 + threadIdx.x) >> 6, waves = (gridDim.x * 256) >> 6;
+    Counters cn; // unused (COUNT=false instantiations below)
+
+    for (uint32_t base = waveId * 64; base < total; base += waves * 64) {
+        const uint32_t q = base + lane;
+        const bool live = q < total;
+        bool emit = false;
+        V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
+        float rtmin = 0.f, rtmax = 0.f;
+        uint32_t rexcl = RT_NONE, a = 0;
+
+        if (live) {
+            a = W.reqX[in][q].y;
+            const uint4 r = W.res[q];
+            uint32_t res_tri = r.x;
+            float res_t = __uint_as_float(r.y), res_l1 = __uint_as_float(r.z), res_l2 = __uint_as_float(r.w);
+
+            uint64_t rng = W.rng[a];
+            uint4 meta = W.meta[a];
+            const float4 oc = W.outc[a];
+            V3 out = xyz(oc);
+            float hit_t = oc.w;
+            uint32_t hit_tri = meta.w;
+            int head = (int)(meta.z & 15u), tail = (int)((meta.z >> 4) & 15u);
+            const uint32_t stage = (meta.z >> 8) & 255u;
+            uint32_t j = meta.z >> 16;
+            float4 c0 = W.cur0[a], c1 = W.cur1[a], c2 = W.cur2[a];
+            V3 cur_o = xyz(c0), cur_d = xyz(c1), cur_w = xyz(c2);
+            float cur_tmin = c0.w;
+            uint32_t cur_excl = __float_as_uint(c1.w);
+            int cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
+            int cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
+
+            // shading state (valid between SHADE_BEGIN and SHADE_END)
+            V3 n = mk(0, 0, 0), where = mk(0, 0, 0), face0 = mk(0, 0, 0), face1 = mk(0, 0, 0), atten = mk(0, 0, 0), toL = mk(0, 0, 0);
+            V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
+            float hit_l1 = 0.f, hit_l2 = 0.f, lmin = 0.f, lmax = 0.f;
+
+            enum { PC_RAY_RESULT, PC_SHADOW_RESULT, PC_LIGHT_SETUP, PC_LIGHT_ACCUM, PC_SHADE_END, PC_NEXT_RAY, PC_EXIT };
+            int pc = PC_RAY_RESULT;
+            if (stage == WS_SHADOW) {
+                const float4 sn = W.shN[a], sw = W.shWhere[a], f0 = W.shF0[a], f1 = W.shF1[a];
+                n = xyz(sn); hit_l1 = sn.w; where = xyz(sw); hit_l2 = sw.w;
+                face0 = xyz(f0); lmin = f0.w; face1 = xyz(f1); lmax = f1.w;
+                atten = xyz(W.shAtt[a]); toL = xyz(W.shToL[a]);
+                tex = xyz(W.shTex[a]); transp = xyz(W.shTransp[a]); refl = xyz(W.shRefl[a]); lum = xyz(W.shLum[a]);
+                pc = PC_SHADOW_RESULT;
+            }
+            bool finished = false, freshShading = false, curDirty = false;
+            uint32_t emitStage = WS_RAY;
+
+            while (pc != PC_EXIT) {
+                if (pc == PC_RAY_RESULT) {
+                    if (res_tri == RT_NONE) { pc = PC_NEXT_RAY; continue; }
+                    // SHADE_BEGIN (:532-561)
+                    hit_tri = res_tri; hit_t = res_t; hit_l1 = res_l1; hit_l2 = res_l2;
+                    const float *shade = S.triShade + 24 * (size_t)hit_tri;
+                    const int m = __float_as_int(shade[21]);
+                    const float *uv = shade + 15;
+                    where = along(cur_o, hit_t, cur_d);
+                    n = shading_normal<false>(S, sh, where, cur_o, cur_d, hit_tri, hit_l1, hit_l2, shade, m, cn);
+                    tex = mk(0, 0, 0); transp = mk(0, 0, 0); refl = mk(0, 0, 0); lum = mk(0, 0, 0);
+                    face0 = mk(0.1f, 0.1f, 0.1f); face1 = mk(0.1f, 0.1f, 0.1f);
+                    if (0 <= m) {
+                        const int mc = CH_COUNT * m;
+                        uint32_t raw, w;
+                        w = S.matSize[2 * (mc + CH_COLOR)];
+                        if (0 < w) tex = texel<false>(S, sh, S.matStart[mc + CH_COLOR], w, S.matSize[2 * (mc + CH_COLOR) + 1], uv, hit_l1, hit_l2, raw, cn);
+                        w = S.matSize[2 * (mc + CH_TRANSPARENCY)];
+                        if (0 < w) transp = texel<false>(S, sh, S.matStart[mc + CH_TRANSPARENCY], w, S.matSize[2 * (mc + CH_TRANSPARENCY) + 1], uv, hit_l1, hit_l2, raw, cn);
+                        w = S.matSize[2 * (mc + CH_REFLECTION)];
+                        if (0 < w) refl = texel<false>(S, sh, S.matStart[mc + CH_REFLECTION], w, S.matSize[2 * (mc + CH_REFLECTION) + 1], uv, hit_l1, hit_l2, raw, cn);
+                        w = S.matSize[2 * (mc + CH_LUMINANCE)];
+                        if (0 < w) lum = texel<false>(S, sh, S.matStart[mc + CH_LUMINANCE], w, S.matSize[2 * (mc + CH_LUMINANCE) + 1], uv, hit_l1, hit_l2, raw, cn);
+                    }
+                    j = 0;
+                    freshShading = true;
+                    pc = PC_LIGHT_SETUP;
+                } else if (pc == PC_LIGHT_SETUP) { // :563-607
+                    if (j >= S.lightCount) { pc = PC_SHADE_END; continue; }
+                    toL = mk(0.f, 0.f, 0.f); atten = mk(1.f, 1.f, 1.f);
+                    lmin = 0.f; lmax = 0.f;
+                    const int type = S.lightType[j];
+                    if (type == 1 || type == 2 || type == 7 || type == 8 || type == 9) {
+                        const V3 r = sphere_point(rng, S.lightRadius[j]);
+                        const float *lp = S.lightPos + 4 * j;
+                        toL.x = r.x + lp[0] - where.x;
+                        toL.y = r.y + lp[1] - where.y;
+                        toL.z = r.z + lp[2] - where.z;
+                        lmax = sqrt_rn(dot3(toL, toL));
+                        const float inv = 1.f / lmax;
+                        toL.x *= inv; toL.y *= inv; toL.z *= inv;
+                    } else if (type >= 3 && type <= 6) {
+                        const float *ld = S.lightDir + 4 * j;
+                        toL = sphere_point(rng, S.lightSpread[j]);
+                        toL.x -= ld[0]; toL.y -= ld[1]; toL.z -= ld[2];
+                        const float inv = 1.f / sqrt_rn(dot3(toL, toL));
+                        toL.x *= inv; toL.y *= inv; toL.z *= inv;
+                        lmax = RT_INF;
+                    }
+                    if (lmin < lmax) { // shadow ray (:608-611): leave the machine until the grid has answered
+                        emit = true; emitStage = WS_SHADOW; ro = where; rd = toL; rtmin = lmin; rtmax = lmax; rexcl = hit_tri;
+                        pc = PC_EXIT;
+                    } else pc = PC_LIGHT_ACCUM;
+                } else if (pc == PC_SHADOW_RESULT) { // :612-626
+                    pc = PC_LIGHT_ACCUM;
+                    if (res_tri != RT_NONE) {
+                        const float *oshade = S.triShade + 24 * (size_t)res_tri;
+                        const int om = __float_as_int(oshade[21]);
+                        V3 tr = mk(0.f, 0.f, 0.f);
+                        if (0 <= om) {
+                            const uint32_t w = S.matSize[2 * (CH_COUNT * om + CH_TRANSPARENCY)];
+                            uint32_t raw;
+                            if (0 < w) tr = texel<false>(S, sh, S.matStart[CH_COUNT * om + CH_TRANSPARENCY], w, S.matSize[2 * (CH_COUNT * om + CH_TRANSPARENCY) + 1], oshade + 15, res_l1, res_l2, raw, cn);
+                        }
+                        atten.x *= tr.x; atten.y *= tr.y; atten.z *= tr.z;
+                        if (0.f < atten.x && 0.f < atten.y && 0.f < atten.z) {
+                            lmin = res_t;
+                            emit = true; emitStage = WS_SHADOW; ro = where; rd = toL; rtmin = lmin; rtmax = lmax; rexcl = hit_tri;
+                            pc = PC_EXIT;
+                        }
+                    }
+                } else if (pc == PC_LIGHT_ACCUM) { // :628-636
+                    const float ndl = dot3(n, toL);
+                    const float mag = __builtin_fabsf(ndl);
+                    const float x = lmax / S.lightHalfAtt[j];
+                    const float fall = __double2float_rn(exp2(-(double)x));
+                    const float e = mag * (fall == fall ? fall : 1.f);
+                    const float *lc = S.lightCol + 4 * j;
+                    if (0.f <= ndl) {
+                        face1.x += (1.f - face1.x) * atten.x * e * lc[0];
+                        face1.y += (1.f - face1.y) * atten.y * e * lc[1];
+                        face1.z += (1.f - face1.z) * atten.z * e * lc[2];
+                    } else {
+                        face0.x += (1.f - face0.x) * atten.x * e * lc[0];
+                        face0.y += (1.f - face0.y) * atten.y * e * lc[1];
+                        face0.z += (1.f - face0.z) * atten.z * e * lc[2];
+                    }
+                    ++j;
+                    pc = PC_LIGHT_SETUP;
+                } else if (pc == PC_SHADE_END) { // :639-723
+                    out.x += (1.f - out.x) * lum.x * cur_w.x;
+                    out.y += (1.f - out.y) * lum.y * cur_w.y;
+                    out.z += (1.f - out.z) * lum.z * cur_w.z;
+                    const int front = (dot3(n, cur_d) <= 0.f) ? 1 : 0;
+                    const V3 lit = front ? face1 : face0;
+                    out.x += (1.f - out.x) * cur_w.x * (1.f - transp.x) * tex.x * lit.x;
+                    out.y += (1.f - out.y) * cur_w.y * (1.f - transp.y) * tex.y * lit.y;
+                    out.z += (1.f - out.z) * cur_w.z * (1.f - transp.z) * tex.z * lit.z;
+                    if (cur_bounces > 0) {
+                        const float total_rt = RT_MAX2(RT_MAX2(refl.x + transp.x, refl.y + transp.y), refl.z + transp.z);
+                        const float dif = (total_rt < 1.f) ? 1.f - total_rt : 0.f;
+                        float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
+                        bool open = true;
+                        V3 w = mk(cur_w.x * tex.x * dif, cur_w.y * tex.y * dif, cur_w.z * tex.z * dif);
+                        if (3.f / 256.f <= w.x + w.y + w.z) { // diffuse bounce (:664-683)
+                            V3 nd = sphere_point(rng, 1.f);
+                            if (front != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
+                            ringA[tail * 3 + 0] = pack4(where, 0.f);
+                            ringA[tail * 3 + 1] = pack4(nd, __uint_as_float(hit_tri));
+                            ringA[tail * 3 + 2] = pack4(w, __uint_as_float(0u));
+                            tail = (tail + 1) % RT_RING;
+                            if ((tail + 1) % RT_RING == head) open = false;
+                        }
+                        if (open) { // mirror (:686-705)
+                            w = mk(cur_w.x * tex.x * refl.x, cur_w.y * tex.y * refl.y, cur_w.z * tex.z * refl.z);
+                            if (3.f / 256.f <= w.x + w.y + w.z) {
+                                const float two = -2.f * dot3(n, cur_d);
+                                const V3 md = mk(cur_d.x + two * n.x, cur_d.y + two * n.y, cur_d.z + two * n.z);
+                                ringA[tail * 3 + 0] = pack4(where, 0.f);
+                                ringA[tail * 3 + 1] = pack4(md, __uint_as_float(hit_tri));
+                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float((uint32_t)(cur_bounces - 1) << 1));
+                                tail = (tail + 1) % RT_RING;
+                                if ((tail + 1) % RT_RING == head) open = false;
+                            }
+                        }
+                        if (open) { // see-through continuation (:707-722)
+                            w = mk(cur_w.x * tex.x * transp.x, cur_w.y * tex.y * transp.y, cur_w.z * tex.z * transp.z);
+                            if (3.f / 256.f <= w.x + w.y + w.z) {
+                                ringA[tail * 3 + 0] = pack4(cur_o, hit_t);
+                                ringA[tail * 3 + 1] = pack4(cur_d, __uint_as_float(hit_tri));
+                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float(((uint32_t)(cur_bounces - 1) << 1) | (uint32_t)cur_fromCamera));
+                                tail = (tail + 1) % RT_RING;
+                            }
+                        }
+                    }
+                    pc = PC_NEXT_RAY;
+                } else { // PC_NEXT_RAY (:509)
+                    head = (head + 1) % RT_RING;
+                    if (head == tail) { finished = true; pc = PC_EXIT; continue; }
+                    const float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
+                    c0 = ringA[head * 3 + 0]; c1 = ringA[head * 3 + 1]; c2 = ringA[head * 3 + 2];
+                    cur_o = xyz(c0); cur_d = xyz(c1); cur_w = xyz(c2);
+                    cur_tmin = c0.w;
+                    cur_excl = __float_as_uint(c1.w);
+                    cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
+                    cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
+                    curDirty = true;
+                    if (cur_fromCamera) {
+                        res_tri = camera_scan(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
+                        pc = PC_RAY_RESULT;
+                    } else {
+                        emit = true; emitStage = WS_RAY; ro = cur_o; rd = cur_d; rtmin = cur_tmin; rtmax = RT_INF; rexcl = cur_excl;
+                        pc = PC_EXIT;
+                    }
+                }
+            }
+
+            if (finished) {
+                W.sampleOut[meta.x] = pack4(out, 0.f);
+            } else {
+                // park the path in HBM until the grid has answered
+                W.rng[a] = rng;
+                W.outc[a] = pack4(out, hit_t);
+                W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | (j << 16), hit_tri);
+                if (curDirty) { // the ray in flight changed (popped from the ring) since the path was loaded
+                    W.cur0[a] = pack4(cur_o, cur_tmin);
+                    W.cur1[a] = pack4(cur_d, __uint_as_float(cur_excl));
+                    W.cur2[a] = pack4(cur_w, __uint_as_float(((uint32_t)cur_bounces << 1) | (uint32_t)cur_fromCamera));
+                }
+                if (emitStage == WS_SHADOW) {
+                    W.shF0[a] = pack4(face0, lmin);
+                    W.shF1[a] = pack4(face1, lmax);
+                    W.shAtt[a] = pack4(atten, 0.f);
+                    W.shToL[a] = pack4(toL, 0.f);
+                    if (freshShading) {
+                        W.shN[a] = pack4(n, hit_l1);
+                        W.shWhere[a] = pack4(where, hit_l2);
+                        W.shTex[a] = pack4(tex, 0.f);
+                        W.shTransp[a] = pack4(transp, 0.f);
+                        W.shRefl[a] = pack4(refl, 0.f);
+                        W.shLum[a] = pack4(lum, 0.f);
+                    }
+                }
+            }
+        }
+        // every lane of the wave arrives here: one atomic per wave for the rays of the next round
+        const uint32_t slot = wave_append(&W.counts[round + 1], emit);
+        if (emit) {
+            W.reqO[outq][slot] = pack4(ro, rtmin);
+            W.reqD[outq][slot] = pack4(rd, rtmax);
+            W.reqX[outq][slot] = make_uint2(rexcl, a);
+        }
+    }
+}
+
+// ---- stage 3: grid traversal, persistent waves with lane refill ---------------------------------------------------------
+// One queued ray per lane (raytrace_opencl.c:324-401).  Per iteration a lane visits ONE cell: occupancy bit from the
+// cached 4x4x4 block word, candidate scan if set, end-cell test, then a branch-free step of the axis with the smallest
+// plane distance (one IEEE divide).  Lanes whose ray ended write the result and refill from the queue.
+#ifndef RT_WF_TRACE_WAVES
+#define RT_WF_TRACE_WAVES 8
+#endif
+#define RT_WF_REFILL_MIN 16
+__global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+{
+    __shared__ float planes[3 * (RT_GRID_DIV + 1)];
+    for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
+    __syncthreads();
+
+    const uint32_t total = W.counts[round];
+    if (total == 0) return;
+    const uint32_t in = round & 1;
+    const float4 *__restrict__ reqO = W.reqO[in];
+    const float4 *__restrict__ reqD = W.reqD[in];
+    const uint2 *__restrict__ reqX = W.reqX[in];
+    uint32_t *cursor = &W.cursors[round];
+    const uint32_t lane = threadIdx.x & 63;
+    const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
+    const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
+
+    bool active = false, exhausted = false;
+    uint32_t q = 0, excluded = RT_NONE, wordAt = 0;
+    unsigned long long word = 0;
+    V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+    float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    int cx = 0, cy = 0, cz = 0, ex = -1, ey = -1, ez = -1;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle == ~0ull || (!exhausted && __popcll(idle) >= RT_WF_REFILL_MIN)) {
+            if (!exhausted) {
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(cursor, want);
+                base = __shfl(base, leader, 64);
+                if (base + want >= total) exhausted = true;
+                if (!active) {
+                    const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (mine < total) {
+                        q = mine;
+                        const float4 ro = reqO[q], rd = reqD[q];
+                        o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
+                        excluded = reqX[q].x;
+                        // start / end cells (:351-362)
+                        V3 from = along(o, tmin, d);
+                        bind_in_cube(from, d, lo, hi);
+                        {
+                            cx = 0; cy = 0; cz = 0;
+#pragma unroll
+                            for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+                                if (planes[cx + div] < from.x) cx += div;
+                                if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
+                                if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
+                            }
+                        }
+                        ex = -1; ey = -1; ez = -1;
+                        if (tmax < RT_INF) {
+                            V3 to = along(o, tmax, d);
+                            bind_in_cube(to, d, lo, hi);
+                            ex = 0; ey = 0; ez = 0;
+#pragma unroll
+                            for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+                                if (planes[ex + div] < to.x) ex += div;
+                                if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
+                                if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
+                            }
+                        }
+                        // distances from the ray ORIGIN to the next plane of each axis (:383-385)
+                        dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
+                        dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
+                        dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
+                        wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+                        word = S.gridBits[wordAt];
+                        active = true;
+                    }
+                }
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            if (active) {
+                uint32_t best = RT_NONE;
+                float tbest = tmax, bl1 = 0.f, bl2 = 0.f; // running maximum is reset per cell (:366)
+                if ((word >> ((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4))) & 1ull) {
+                    const uint32_t id = (uint32_t)(cx + RT_GRID_DIV * cy + RT_GRID_DIV * RT_GRID_DIV * cz);
+                    const uint32_t first = S.gridStart[id], last = S.gridStart[id + 1];
+                    for (uint32_t i = first; i < last; ++i) {
+                        const uint32_t tri = S.gridList[i];
+                        if (excluded != tri) {
+                            float t, l1, l2;
+                            if (tri_test(S.triRec, tri, o, d, tmin, tbest, t, l1, l2)) {
+                                best = tri; tbest = t; bl1 = l1; bl2 = l2;
+                            }
+                        }
+                    }
+                }
+                // first cell with a hit ends the walk, as does the end cell (:380-381)
+                bool done = (best != RT_NONE) || (cx == ex && cy == ey && cz == ez);
+                if (!done) {
+                    // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
+                    const bool sxm = (dx < dy) & (dx < dz);
+                    const bool sym = !sxm & (dy < dz);
+                    const float dd = sxm ? d.x : (sym ? d.y : d.z);
+                    const float oo = sxm ? o.x : (sym ? o.y : o.z);
+                    int c = sxm ? cx : (sym ? cy : cz);
+                    const int pos = (0 <= dd) ? 1 : 0;
+                    c += pos ? 1 : -1;
+                    done = (c < 0) | (RT_GRID_DIV <= c);
+                    if (!done) {
+                        const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
+                        const float nd = (planes[axisBase + c + pos] - oo) / dd;
+                        cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
+                        dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
+                        const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+                        if (at != wordAt) { wordAt = at; word = S.gridBits[at]; }
+                    }
+                }
+                if (done) {
+                    W.res[q] = make_uint4(best, __float_as_uint(tbest), __float_as_uint(bl1), __float_as_uint(bl2));
+                    active = false;
+                }
+            }
+        }
+    }
+}
+
+// ---- stage 4: samples -> u16 planes -----------------------------------------------------------------------------------
+// One thread per pixel of the instance's tiles, row-major inside the tile (coalesced 2-byte stores).  Samples are added
+// in order, each addend truncated on its own, saturating (raytrace_opencl.c:726-741); `first` starts from zero, later
+// sample batches continue from the tile buffer.
+__global__ __launch_bounds__(256) void wf_accum_kernel(const RtDevScene S, const RtWavefront W, const int first)
+{
+    const uint32_t localPixel = blockIdx.x * 256 + threadIdx.x;
+    if (localPixel >= S.tileCount * RT_TILE_PIXELS) return;
+    const uint32_t slot = localPixel / RT_TILE_PIXELS, inTile = localPixel % RT_TILE_PIXELS;
+    const uint32_t tile = S.tileIds[slot];
+    const uint32_t gx = (tile % S.tilesX) * RT_TILE + (inTile % RT_TILE), gy = (tile / S.tilesX) * RT_TILE + (inTile / RT_TILE);
+    if (gx >= S.width || gy >= S.height) return;
+    uint16_t *planes = S.tileBuf + (size_t)slot * 3 * RT_TILE_PIXELS + inTile;
+    int r = 0, g = 0, b = 0;
+    if (!first) { r = planes[0]; g = planes[RT_TILE_PIXELS]; b = planes[2 * RT_TILE_PIXELS]; }
+    const float scale = (float)(0xFFFF) / (float)S.sampleCount; // :728
+    for (uint32_t sb = 0; sb < W.samplesInBatch; ++sb) {
+        const float4 c = W.sampleOut[localPixel * W.samplesInBatch + sb];
+        r = sat_add_u16(r, c.x, scale);
+        g = sat_add_u16(g, c.y, scale);
+        b = sat_add_u16(b, c.z, scale);
+    }
+    planes[0] = (uint16_t)r;
+    planes[RT_TILE_PIXELS] = (uint16_t)g;
+    planes[2 * RT_TILE_PIXELS] = (uint16_t)b;
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------------------------
+extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream)
+{
+    if (scene->tileCount == 0) return hipSuccess;
+    hipLaunchKernelGGL(wf_primary_kernel, dim3(scene->tileCount * 64, wf->samplesInBatch), dim3(256), 0, stream, *scene, *wf);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wf_logic_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream)
+{
+    const uint32_t n = scene->tileCount * RT_TILE_PIXELS;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(wf_accum_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *scene, *wf, first);
+    return hipGetLastError();
+}

@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_HIP_LIB selects another build of the same library (kernel A/B experiments); default is the in-tree build.
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "libraytrace_hip.so")
 TILE = 128
+PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1
 
 
 class Float3(C.Structure):  # cl_float3 == cl_float4: 16 bytes, passed as two SSE eightbytes on SysV
@@ -62,6 +63,7 @@ DROPIN_SYMBOLS = [
 ]
 RESIDENT_SYMBOLS = [
     "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles",
+    "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildSceneGrid", "rtHipFree",
 ]
@@ -119,6 +121,9 @@ def lib() -> C.CDLL:
     L.rtHipSceneBytes.argtypes = [vp]
     L.rtHipRenderTiles.argtypes = [vp, vp]
     L.rtHipRenderTilesCounted.argtypes = [vp, C.POINTER(Stats)]
+    L.rtHipSetPipeline.argtypes = [vp, C.c_int]
+    L.rtHipStageTiming.argtypes = [vp, C.c_int]
+    L.rtHipStageTimes.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
     L.rtHipTileBuffer.restype = vp
     L.rtHipTileBuffer.argtypes = [vp]
     L.rtHipTileBufferBytes.restype = u64
@@ -297,6 +302,18 @@ class ResidentScene:
 
     def render(self, stream: int = 0):
         self._check(lib().rtHipRenderTiles(self.handle, stream or None), "rtHipRenderTiles")
+
+    def set_pipeline(self, pipeline: int):
+        self._check(lib().rtHipSetPipeline(self.handle, pipeline), "rtHipSetPipeline")
+
+    def stage_timing(self, enable: bool):
+        self._check(lib().rtHipStageTiming(self.handle, 1 if enable else 0), "rtHipStageTiming")
+
+    def stage_times_ms(self):
+        """Sum over the frames since stage_timing(True): dict of stage -> ms, and rounds of the last frame."""
+        ms, rounds = (C.c_double * 4)(), C.c_uint64()
+        self._check(lib().rtHipStageTimes(self.handle, C.byref(ms), C.byref(rounds)), "rtHipStageTimes")
+        return dict(primary=ms[0], logic=ms[1], trace=ms[2], accum=ms[3]), rounds.value
 
     def render_counted(self) -> dict:
         st = Stats()

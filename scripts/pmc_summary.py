@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "?")
-        if "rt_" not in k:
+        if "rt_" not in k and "wf_" not in k:
             continue
         acc[k.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in sorted(acc.items()):
