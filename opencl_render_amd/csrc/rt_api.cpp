@@ -25,12 +25,14 @@
 extern "C" hipError_t rtk_launch_trace(const RtDevScene *scene, int counted, hipStream_t stream);
 extern "C" hipError_t rtk_launch_prepare(uint32_t triangleCount, const void *vertex, const void *triIndex, const void *triMaterial,
                                          const void *triUv, const void *triNormal, float *triRec, float *triShade, hipStream_t stream);
+extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const float *triRec, float *pairRec, hipStream_t stream);
 extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
                                         uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream);
 
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
+                                       uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
 
 namespace {
@@ -237,6 +239,38 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                     if (d->gridStart[row + x] != d->gridStart[row + x + 1]) w[x >> 2] |= 1ull << (shift | (x & 3));
             }
         if (sc->upload(bits.data(), bits.size(), &D.gridBits, "gridBits")) return -1;
+        // dense view: rank per block, first pair per non-empty cell (in block order, bit order inside a block), pairs
+        {
+            const size_t blocks = bits.size();
+            std::vector<uint32_t> rank(blocks), cellFirst, pairTri;
+            cellFirst.reserve(listSize + 1);
+            pairTri.reserve(listSize);
+            uint32_t running = 0;
+            for (size_t b = 0; b < blocks; ++b) {
+                rank[b] = running;
+                unsigned long long w = bits[b];
+                const uint32_t bx = (uint32_t)(b % 64), by = (uint32_t)((b / 64) % 64), bz = (uint32_t)(b / 4096);
+                while (w) {
+                    const int bit = __builtin_ctzll(w);
+                    w &= w - 1;
+                    const uint32_t cx = bx * 4 + (bit & 3), cy = by * 4 + ((bit >> 2) & 3), cz = bz * 4 + (bit >> 4);
+                    const uint64_t cell = cx + (uint64_t)RT_GRID_DIV * cy + (uint64_t)RT_GRID_DIV * RT_GRID_DIV * cz;
+                    cellFirst.push_back((uint32_t)pairTri.size());
+                    for (uint32_t i = d->gridStart[cell]; i < d->gridStart[cell + 1]; ++i) pairTri.push_back(d->gridList[i]);
+                    ++running;
+                }
+            }
+            cellFirst.push_back((uint32_t)pairTri.size());
+            if (pairTri.size() != listSize) return fail("internal: pair count %zu != list size %llu", pairTri.size(), (unsigned long long)listSize);
+            if (sc->upload(rank.data(), rank.size(), &D.gridRank, "gridRank")) return -1;
+            if (sc->upload(cellFirst.data(), cellFirst.size(), &D.cellFirst, "cellFirst")) return -1;
+            if (sc->upload(pairTri.data(), pairTri.size(), &D.pairTri, "pairTri")) return -1;
+            float *pairRec = nullptr;
+            if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
+            HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, D.pairTri, D.triRec, pairRec, sc->stream));
+            D.pairRec = pairRec;
+            HIP_OK(hipStreamSynchronize(sc->stream));
+        }
         HIP_OK(hipStreamSynchronize(sc->stream));
     }
 
@@ -307,7 +341,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, sc->device));
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16;
+        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16 + 2 * 32;
         const uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
@@ -327,12 +361,15 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             sc->alloc<float4>(cap, &Wf.reqO[0]) || sc->alloc<float4>(cap, &Wf.reqO[1]) || sc->alloc<float4>(cap, &Wf.reqD[0]) ||
             sc->alloc<float4>(cap, &Wf.reqD[1]) || sc->alloc<uint2>(cap, &Wf.reqX[0]) || sc->alloc<uint2>(cap, &Wf.reqX[1]) ||
             sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(cap, &Wf.sampleOut) ||
-            sc->alloc<uint32_t>(2 * (RT_WF_MAX_ROUNDS + 2), &Wf.counts))
+            sc->alloc<uint4>(cap * 2, &Wf.cont[0]) || sc->alloc<uint4>(cap * 2, &Wf.cont[1]) ||
+            sc->alloc<uint32_t>((uint64_t)(RT_WF_MAX_ROUNDS + 2) * (1 + 2 * RT_WF_PASSES), &Wf.counts))
             return -1;
         Wf.cursors = Wf.counts + (RT_WF_MAX_ROUNDS + 2);
+        Wf.contCounts = Wf.cursors + (size_t)(RT_WF_MAX_ROUNDS + 2) * RT_WF_PASSES;
         HIP_OK(hipHostMalloc((void **)&sc->hostCount, 64, hipHostMallocDefault));
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        sc->traceBlocks = cus * 8;                      // 8 waves/SIMD x 4 SIMDs = 8 four-wave workgroups per CU, all resident
+        sc->traceBlocks = (uint32_t)((cap + 255) / 256);  // one workgroup per 256 queue entries; surplus groups exit at once
+        (void)cus;
         sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
         if (sc->logicBlocks == 0) sc->logicBlocks = 1;
         const char *env = getenv("RT_HIP_PIPELINE");
@@ -370,14 +407,17 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
     for (uint32_t base = 0; base < D.sampleCount; base += sc->samplesPerBatch) {
         Wf.sampleBase = base;
         Wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, D.sampleCount - base);
-        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * 2 * (RT_WF_MAX_ROUNDS + 2), st));
+        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * (size_t)(RT_WF_MAX_ROUNDS + 2) * (1 + 2 * RT_WF_PASSES), st));
         HIP_OK(stage(0, [&] { return rtw_launch_primary(&D, &Wf, st); }));
         uint32_t r = 0;
         for (;;) {
             const uint32_t chunk = 4;
             for (uint32_t k = 0; k < chunk && r < RT_WF_MAX_ROUNDS; ++k, ++r) {
                 HIP_OK(stage(1, [&] { return rtw_launch_logic(&D, &Wf, r, sc->logicBlocks, st); }));
-                HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, sc->traceBlocks, st); }));
+                // cell-visit budgets per pass: a walk has at most 766 visits, the last pass is unbounded anyway
+                static const uint32_t budgets[RT_WF_PASSES] = { 64, 128, 256, 0xffffffffu };
+                for (uint32_t p = 0; p < RT_WF_PASSES; ++p)
+                    HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, p, budgets[p], sc->traceBlocks, st); }));
             }
             HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + r, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));

@@ -43,6 +43,14 @@ struct RtDevScene {
     // + 4096*(cz>>2), bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 set iff the cell's list is non-empty.  Lets the DDA walk
     // empty space without touching the 67 MB gridStart array; empty cells have no effect on the result.
     const unsigned long long *gridBits;
+    // Dense view of the same grid for the wavefront trace kernel (no 67 MB sparse array, no list->record hop):
+    //   gridRank[block]  number of non-empty cells in all blocks before `block`          (1 MiB, L2-resident)
+    //   dense cell id    k = gridRank[block] + popcount(word & ((1<<bit)-1))
+    //   cellFirst[k..k+1] range of the cell's (cell, triangle) pairs                      (4 B per non-empty cell)
+    //   pairTri[i]       triangle id of pair i (ascending inside a cell, as in scenePixelTriangleList)
+    //   pairRec[i]       that triangle's 64-byte record, replicated per pair so a cell's candidates are contiguous
+    const uint32_t *gridRank, *cellFirst, *pairTri;
+    const float *pairRec;
     // materials
     uint32_t materialCount, texelCount;
     const uint32_t *matSize; // 2 x 5 per material
@@ -67,6 +75,7 @@ struct RtDevScene {
 //   round r:   logic(r)  reads  req[r&1].path + res[q]   for q < counts[r]      -> appends to req[(r+1)&1], counts[r+1]
 //              trace(r+1) reads req[(r+1)&1][q]           for q < counts[r+1]    -> writes res[q]
 #define RT_WF_MAX_ROUNDS 4094
+#define RT_WF_PASSES 4        // trace passes per round; the last one runs every ray to its end
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
@@ -84,7 +93,13 @@ struct RtWavefront {
     uint2 *reqX[2];            // excluded triangle, path id
     uint4 *res;                // hit triangle (0xffffffff = none), t, l1, l2 (float bits)
     uint32_t *counts;          // [RT_WF_MAX_ROUNDS+2] queue length per round (zeroed per batch)
-    uint32_t *cursors;         // [RT_WF_MAX_ROUNDS+2] trace-kernel fetch cursor per round
+    // Grid walks are resumable: a trace PASS gives every ray a bounded number of cell steps; rays still walking are
+    // written to a continuation queue (DDA state only, the ray itself stays in req*) and the next pass runs them
+    // re-packed into full waves.  Per (round, pass): cursors = fetch cursor over the pass's input queue,
+    // contCounts = entries the pass appended to its output queue.
+    uint32_t *cursors;         // (unused by the workgroup-per-chunk trace kernel; kept zeroed)
+    uint32_t *contCounts;      // [(RT_WF_MAX_ROUNDS+2) * RT_WF_PASSES]
+    uint4 *cont[2];            // [capacity][2]: {q, cx|cy<<8|cz<<16, ex|ey<<8|ez<<16|hasEnd<<24, -} {dx, dy, dz, -}
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

@@ -346,7 +346,26 @@ __global__ __launch_bounds__(256) void rt_detile_kernel(const uint16_t *__restri
     }
 }
 
+// Replicates triangle records in (cell, triangle) pair order: pairRec[i] = triRec[pairTri[i]].  One thread per float4.
+__global__ __launch_bounds__(256) void rt_gather_pair_records(uint32_t pairCount, const uint32_t *__restrict__ pairTri,
+                                                              const float4 *__restrict__ triRec, float4 *__restrict__ pairRec)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (uint64_t)pairCount * 4) return;
+    const uint32_t pair = (uint32_t)(gid >> 2), part = (uint32_t)(gid & 3);
+    pairRec[gid] = triRec[(size_t)pairTri[pair] * 4 + part];
+}
+
 // ---- launch wrappers (called from rt_api.cpp; keep every <<< >>> in this translation unit) -----------------------
+extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const float *triRec, float *pairRec, hipStream_t stream)
+{
+    if (pairCount == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)pairCount * 4;
+    hipLaunchKernelGGL(rt_gather_pair_records, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, pairCount, pairTri,
+                       (const float4 *)triRec, (float4 *)pairRec);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t rtk_launch_trace(const RtDevScene *scene, int counted, hipStream_t stream)
 {
     const uint32_t blocks = scene->tileCount * 64;

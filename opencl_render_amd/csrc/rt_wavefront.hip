@@ -362,137 +362,172 @@ __global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const
     }
 }
 
-// ---- stage 3: grid traversal, persistent waves with lane refill ---------------------------------------------------------
-// One queued ray per lane (raytrace_opencl.c:324-401).  Per iteration a lane visits ONE cell: occupancy bit from the
-// cached 4x4x4 block word, candidate scan if set, end-cell test, then a branch-free step of the axis with the smallest
-// plane distance (one IEEE divide).  Lanes whose ray ended write the result and refill from the queue.
+// ---- stage 3: grid traversal in resumable passes -----------------------------------------------------------------------
+// One queued ray per lane (raytrace_opencl.c:324-401); one workgroup per 256 queue entries, no fetch atomics.
+// Per iteration a lane visits ONE cell: occupancy bit from the cached 4x4x4 block word; a lane on an occupied cell parks
+// until enough lanes of its wave are parked, then they scan their cells' (contiguous) candidate records together;
+// end-cell test; branch-free step of the axis with the smallest plane distance (one IEEE divide).
+// A ray gets `budget` cell visits per pass.  Rays still walking when it runs out are appended to the continuation
+// queue (one atomic per workgroup, aggregated through LDS) and resumed by the next pass re-packed into full waves.
+// Results do not depend on where a walk is cut: the continuation carries the exact DDA state (cell, end cell, the three
+// plane distances); the ray itself stays in the request arrays.
 #ifndef RT_WF_TRACE_WAVES
 #define RT_WF_TRACE_WAVES 8
 #endif
-#define RT_WF_REFILL_MIN 16
-__global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+#ifndef RT_WF_SCAN_MIN
+#define RT_WF_SCAN_MIN 24         // scan parked lanes once this many wait on an occupied cell ...
+#endif
+#ifndef RT_WF_STEP_MIN
+#define RT_WF_STEP_MIN 20         // ... or when fewer than this many lanes are still stepping
+#endif
+template <bool FRESH>
+__global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
+                                                                         const uint32_t pass, const uint32_t budgetPerRay)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
+    __shared__ uint32_t spillWave[4], spillBase;
+
+    const uint32_t slotId = round * RT_WF_PASSES + pass;
+    // input: the round's fresh requests (pass 0) or what the previous pass spilled
+    const uint32_t total = FRESH ? W.counts[round] : W.contCounts[slotId - 1];
+    const uint32_t mine = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= total) return; // whole workgroup beyond the queue
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
-    const uint32_t total = W.counts[round];
-    if (total == 0) return;
     const uint32_t in = round & 1;
-    const float4 *__restrict__ reqO = W.reqO[in];
-    const float4 *__restrict__ reqD = W.reqD[in];
-    const uint2 *__restrict__ reqX = W.reqX[in];
-    uint32_t *cursor = &W.cursors[round];
-    const uint32_t lane = threadIdx.x & 63;
+    const uint4 *__restrict__ contIn = W.cont[(pass + 1) & 1];
+    uint4 *__restrict__ contOut = W.cont[pass & 1];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
     const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
 
-    bool active = false, exhausted = false;
-    uint32_t q = 0, excluded = RT_NONE, wordAt = 0;
+    bool active = mine < total, pending = false;
+    uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0, first = 0, last = 0;
     unsigned long long word = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
     int cx = 0, cy = 0, cz = 0, ex = -1, ey = -1, ez = -1;
 
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        if (idle == ~0ull || (!exhausted && __popcll(idle) >= RT_WF_REFILL_MIN)) {
-            if (!exhausted) {
-                const uint32_t want = (uint32_t)__popcll(idle);
-                const int leader = __ffsll((long long)idle) - 1;
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(cursor, want);
-                base = __shfl(base, leader, 64);
-                if (base + want >= total) exhausted = true;
-                if (!active) {
-                    const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (mine < total) {
-                        q = mine;
-                        const float4 ro = reqO[q], rd = reqD[q];
-                        o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
-                        excluded = reqX[q].x;
-                        // start / end cells (:351-362)
-                        V3 from = along(o, tmin, d);
-                        bind_in_cube(from, d, lo, hi);
-                        {
-                            cx = 0; cy = 0; cz = 0;
+    if (active) {
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
+        if (FRESH) q = mine;
+        else { c0 = contIn[2 * (size_t)mine]; c1 = contIn[2 * (size_t)mine + 1]; q = c0.x; }
+        const float4 ro = W.reqO[in][q], rd = W.reqD[in][q];
+        o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
+        excluded = W.reqX[in][q].x;
+        if (FRESH) {
+            // start / end cells (:351-362)
+            V3 from = along(o, tmin, d);
+            bind_in_cube(from, d, lo, hi);
 #pragma unroll
-                            for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-                                if (planes[cx + div] < from.x) cx += div;
-                                if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
-                                if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
-                            }
-                        }
-                        ex = -1; ey = -1; ez = -1;
-                        if (tmax < RT_INF) {
-                            V3 to = along(o, tmax, d);
-                            bind_in_cube(to, d, lo, hi);
-                            ex = 0; ey = 0; ez = 0;
+            for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+                if (planes[cx + div] < from.x) cx += div;
+                if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
+                if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
+            }
+            if (tmax < RT_INF) {
+                V3 to = along(o, tmax, d);
+                bind_in_cube(to, d, lo, hi);
+                ex = 0; ey = 0; ez = 0;
 #pragma unroll
-                            for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-                                if (planes[ex + div] < to.x) ex += div;
-                                if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
-                                if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
-                            }
-                        }
-                        // distances from the ray ORIGIN to the next plane of each axis (:383-385)
-                        dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
-                        dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
-                        dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
-                        wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-                        word = S.gridBits[wordAt];
-                        active = true;
-                    }
+                for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+                    if (planes[ex + div] < to.x) ex += div;
+                    if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
+                    if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
                 }
             }
-            if (__ballot(active) == 0ull) break;
+            // distances from the ray ORIGIN to the next plane of each axis (:383-385)
+            dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
+            dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
+            dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
+        } else {
+            cx = (int)(c0.y & 255u); cy = (int)((c0.y >> 8) & 255u); cz = (int)((c0.y >> 16) & 255u);
+            if (c0.z >> 24) { ex = (int)(c0.z & 255u); ey = (int)((c0.z >> 8) & 255u); ez = (int)((c0.z >> 16) & 255u); }
+            dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z);
         }
+        wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+        word = S.gridBits[wordAt];
+        wordRank = S.gridRank[wordAt];
+    }
 
+    uint32_t budget = budgetPerRay;
 #pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-            if (active) {
-                uint32_t best = RT_NONE;
-                float tbest = tmax, bl1 = 0.f, bl2 = 0.f; // running maximum is reset per cell (:366)
-                if ((word >> ((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4))) & 1ull) {
-                    const uint32_t id = (uint32_t)(cx + RT_GRID_DIV * cy + RT_GRID_DIV * RT_GRID_DIV * cz);
-                    const uint32_t first = S.gridStart[id], last = S.gridStart[id + 1];
-                    for (uint32_t i = first; i < last; ++i) {
-                        const uint32_t tri = S.gridList[i];
-                        if (excluded != tri) {
-                            float t, l1, l2;
-                            if (tri_test(S.triRec, tri, o, d, tmin, tbest, t, l1, l2)) {
-                                best = tri; tbest = t; bl1 = l1; bl2 = l2;
-                            }
+    for (;;) {
+        const bool walking = active && budget != 0;
+        if (walking && !pending) {
+            const uint32_t bit = (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4));
+            if ((word >> bit) & 1ull) {
+                // park, and fetch the cell's pair range now: it is in registers by the time the wave scans
+                const uint32_t k = wordRank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+                first = S.cellFirst[k];
+                last = S.cellFirst[k + 1];
+                pending = true;
+            }
+        }
+        const int parked = __popcll(__ballot(walking && pending));
+        const int moving = __popcll(__ballot(walking && !pending));
+        if (parked + moving == 0) break;
+        const bool scanNow = parked >= RT_WF_SCAN_MIN || moving < RT_WF_STEP_MIN;
+        if (walking && (!pending || scanNow)) {
+            uint32_t best = RT_NONE;
+            float tbest = tmax, bl1 = 0.f, bl2 = 0.f; // running maximum is reset per cell (:366)
+            if (pending) {
+                for (uint32_t i = first; i < last; ++i) {
+                    const uint32_t tri = S.pairTri[i];
+                    if (excluded != tri) {
+                        float t, l1, l2;
+                        if (tri_test(S.pairRec, i, o, d, tmin, tbest, t, l1, l2)) {
+                            best = tri; tbest = t; bl1 = l1; bl2 = l2;
                         }
                     }
                 }
-                // first cell with a hit ends the walk, as does the end cell (:380-381)
-                bool done = (best != RT_NONE) || (cx == ex && cy == ey && cz == ez);
+                pending = false;
+            }
+            --budget;
+            // first cell with a hit ends the walk, as does the end cell (:380-381)
+            bool done = (best != RT_NONE) || (cx == ex && cy == ey && cz == ez);
+            if (!done) {
+                // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
+                const bool sxm = (dx < dy) & (dx < dz);
+                const bool sym = !sxm & (dy < dz);
+                const float dd = sxm ? d.x : (sym ? d.y : d.z);
+                const float oo = sxm ? o.x : (sym ? o.y : o.z);
+                int c = sxm ? cx : (sym ? cy : cz);
+                const int pos = (0 <= dd) ? 1 : 0;
+                c += pos ? 1 : -1;
+                done = (c < 0) | (RT_GRID_DIV <= c);
                 if (!done) {
-                    // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
-                    const bool sxm = (dx < dy) & (dx < dz);
-                    const bool sym = !sxm & (dy < dz);
-                    const float dd = sxm ? d.x : (sym ? d.y : d.z);
-                    const float oo = sxm ? o.x : (sym ? o.y : o.z);
-                    int c = sxm ? cx : (sym ? cy : cz);
-                    const int pos = (0 <= dd) ? 1 : 0;
-                    c += pos ? 1 : -1;
-                    done = (c < 0) | (RT_GRID_DIV <= c);
-                    if (!done) {
-                        const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
-                        const float nd = (planes[axisBase + c + pos] - oo) / dd;
-                        cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
-                        dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
-                        const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-                        if (at != wordAt) { wordAt = at; word = S.gridBits[at]; }
-                    }
-                }
-                if (done) {
-                    W.res[q] = make_uint4(best, __float_as_uint(tbest), __float_as_uint(bl1), __float_as_uint(bl2));
-                    active = false;
+                    const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
+                    const float nd = (planes[axisBase + c + pos] - oo) / dd;
+                    cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
+                    dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
+                    const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+                    if (at != wordAt) { wordAt = at; word = S.gridBits[at]; wordRank = S.gridRank[at]; }
                 }
             }
+            if (done) {
+                W.res[q] = make_uint4(best, __float_as_uint(tbest), __float_as_uint(bl1), __float_as_uint(bl2));
+                active = false;
+            }
         }
+    }
+
+    // rays that are still walking leave through the continuation queue: one atomic per workgroup
+    const unsigned long long spillMask = __ballot(active);
+    if (lane == 0) spillWave[wave] = (uint32_t)__popcll(spillMask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = spillWave[0] + spillWave[1] + spillWave[2] + spillWave[3];
+        spillBase = n ? atomicAdd(&W.contCounts[slotId], n) : 0u;
+    }
+    __syncthreads();
+    if (active) {
+        uint32_t at = spillBase + (uint32_t)__popcll(spillMask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) at += spillWave[w];
+        const uint32_t endBits = (ex < 0) ? 0u : ((uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16) | (1u << 24));
+        contOut[2 * (size_t)at + 0] = make_uint4(q, (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16), endBits, 0u);
+        contOut[2 * (size_t)at + 1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), 0u);
     }
 }
 
@@ -537,9 +572,11 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
+                                       uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    if (pass == 0) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
+    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
     return hipGetLastError();
 }
 
