@@ -73,6 +73,7 @@ struct rtHipScene {
     int pipeline = RT_HIP_PIPELINE_WAVEFRONT;
     RtWavefront wf{};
     uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
+    uint32_t passCount = 4, passBudget[RT_WF_PASSES] = { 64, 128, 256, 0xffffffffu };
     uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum]
     struct StageEvent { int stage; hipEvent_t a, b; };
@@ -262,12 +263,24 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             }
             cellFirst.push_back((uint32_t)pairTri.size());
             if (pairTri.size() != listSize) return fail("internal: pair count %zu != list size %llu", pairTri.size(), (unsigned long long)listSize);
-            if (sc->upload(rank.data(), rank.size(), &D.gridRank, "gridRank")) return -1;
-            if (sc->upload(cellFirst.data(), cellFirst.size(), &D.cellFirst, "cellFirst")) return -1;
-            if (sc->upload(pairTri.data(), pairTri.size(), &D.pairTri, "pairTri")) return -1;
+            std::vector<uint32_t> block(blocks * 3);
+            for (size_t b = 0; b < blocks; ++b) {
+                block[3 * b + 0] = (uint32_t)(bits[b] & 0xffffffffull);
+                block[3 * b + 1] = (uint32_t)(bits[b] >> 32);
+                block[3 * b + 2] = rank[b];
+            }
+            std::vector<uint2> range(cellFirst.size() - 1);
+            for (size_t k = 0; k + 1 < cellFirst.size(); ++k) range[k] = make_uint2(cellFirst[k], cellFirst[k + 1]);
+            if (sc->upload(block.data(), block.size(), &D.gridBlock, "gridBlock")) return -1;
+            if (sc->upload(range.data(), range.size(), &D.cellRange, "cellRange")) return -1;
+            uint32_t *dPairTri = nullptr;
+            HIP_OK(hipMalloc((void **)&dPairTri, (size_t)(listSize ? listSize : 1) * 4));
+            if (listSize) HIP_OK(hipMemcpyAsync(dPairTri, pairTri.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
             float *pairRec = nullptr;
             if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
-            HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, D.pairTri, D.triRec, pairRec, sc->stream));
+            HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, dPairTri, D.triRec, pairRec, sc->stream));
+            HIP_OK(hipStreamSynchronize(sc->stream));
+            HIP_OK(hipFree(dPairTri));
             D.pairRec = pairRec;
             HIP_OK(hipStreamSynchronize(sc->stream));
         }
@@ -372,6 +385,18 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         (void)cus;
         sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
         if (sc->logicBlocks == 0) sc->logicBlocks = 1;
+        if (const char *b = getenv("RT_WF_BUDGETS")) { // tuning aid: comma-separated cell-visit budgets; a final unbounded pass is appended
+            uint32_t n = 0;
+            while (*b && n < RT_WF_PASSES - 1) {
+                char *endp = nullptr;
+                const unsigned long v = strtoul(b, &endp, 10);
+                if (endp == b) break;
+                sc->passBudget[n++] = v ? (uint32_t)v : 1u;
+                b = (*endp == ',') ? endp + 1 : endp;
+            }
+            sc->passBudget[n++] = 0xffffffffu;
+            sc->passCount = n;
+        }
         const char *env = getenv("RT_HIP_PIPELINE");
         if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     }
@@ -414,10 +439,9 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
             const uint32_t chunk = 4;
             for (uint32_t k = 0; k < chunk && r < RT_WF_MAX_ROUNDS; ++k, ++r) {
                 HIP_OK(stage(1, [&] { return rtw_launch_logic(&D, &Wf, r, sc->logicBlocks, st); }));
-                // cell-visit budgets per pass: a walk has at most 766 visits, the last pass is unbounded anyway
-                static const uint32_t budgets[RT_WF_PASSES] = { 64, 128, 256, 0xffffffffu };
-                for (uint32_t p = 0; p < RT_WF_PASSES; ++p)
-                    HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, p, budgets[p], sc->traceBlocks, st); }));
+                // cell-visit budgets per pass: a walk has at most 766 visits; the last pass is unbounded
+                for (uint32_t p = 0; p < sc->passCount; ++p)
+                    HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, p, sc->passBudget[p], sc->traceBlocks, st); }));
             }
             HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + r, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));

@@ -43,13 +43,17 @@ struct RtDevScene {
     // + 4096*(cz>>2), bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 set iff the cell's list is non-empty.  Lets the DDA walk
     // empty space without touching the 67 MB gridStart array; empty cells have no effect on the result.
     const unsigned long long *gridBits;
-    // Dense view of the same grid for the wavefront trace kernel (no 67 MB sparse array, no list->record hop):
-    //   gridRank[block]  number of non-empty cells in all blocks before `block`          (1 MiB, L2-resident)
-    //   dense cell id    k = gridRank[block] + popcount(word & ((1<<bit)-1))
-    //   cellFirst[k..k+1] range of the cell's (cell, triangle) pairs                      (4 B per non-empty cell)
-    //   pairTri[i]       triangle id of pair i (ascending inside a cell, as in scenePixelTriangleList)
-    //   pairRec[i]       that triangle's 64-byte record, replicated per pair so a cell's candidates are contiguous
-    const uint32_t *gridRank, *cellFirst, *pairTri;
+    // Dense view of the same grid for the wavefront trace kernel (no 67 MB sparse array, no list->record hop), shaped so
+    // a cell visit costs as few divergent load instructions as possible (the texture addresser is the bottleneck):
+    //   gridBlock[block]  {occupancy word lo, hi, rank}: rank = number of non-empty cells in all blocks before `block`
+    //                     (12 B, one dwordx3 load per block entered; 3 MiB, L2-resident)
+    //   dense cell id     k = rank + popcount(word & ((1<<bit)-1))
+    //   cellRange[k]      {first, last} pair index range of the cell (one 8-byte load)
+    //   pairRec[i]        64-byte record of pair i, replicated per (cell, triangle) pair so a cell's candidates are
+    //                     contiguous: {a.xyz, triangleId} {n.xyz, -} {ab.xyz, abab} {ac.xyz, acac}
+    //                     (plane test = first two float4; abac and 1/(abac^2-abab*acac) are recomputed when needed)
+    const uint32_t *gridBlock;
+    const uint2 *cellRange;
     const float *pairRec;
     // materials
     uint32_t materialCount, texelCount;
@@ -75,7 +79,7 @@ struct RtDevScene {
 //   round r:   logic(r)  reads  req[r&1].path + res[q]   for q < counts[r]      -> appends to req[(r+1)&1], counts[r+1]
 //              trace(r+1) reads req[(r+1)&1][q]           for q < counts[r+1]    -> writes res[q]
 #define RT_WF_MAX_ROUNDS 4094
-#define RT_WF_PASSES 4        // trace passes per round; the last one runs every ray to its end
+#define RT_WF_PASSES 8        // at most this many trace passes per round; the last one runs every ray to its end
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)

@@ -58,6 +58,36 @@ __device__ __forceinline__ uint32_t camera_scan(const RtDevScene &S, uint32_t lo
     return hit_tri;
 }
 
+// Triangle test against a (cell, triangle) pair record (rt_device.h): same arithmetic as tri_test / the reference
+// (raytrace_opencl.c:124-172), two 16-byte loads for the plane test, two more only when t is in range.
+__device__ __forceinline__ bool pair_test(const float4 *__restrict__ rec, V3 o, V3 d, float tmin, float tmax, uint32_t excluded,
+                                          uint32_t &tri, float &t, float &l1, float &l2)
+{
+    const float4 r0 = rec[0];
+    tri = __float_as_uint(r0.w);
+    if (tri == excluded) return false;
+    const float4 r1 = rec[1];
+    const V3 a = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z);
+    const V3 ao = sub3(o, a);
+    t = -dot3(n, ao) / dot3(n, d);
+    bool hit = false;
+    if (tmin < t && t < tmax) {
+        const float4 r2 = rec[2], r3 = rec[3];
+        const V3 ab = mk(r2.x, r2.y, r2.z), ac = mk(r3.x, r3.y, r3.z);
+        const float abab = r2.w, abac = dot3(ab, ac), acac = r3.w; // dot(ab,ac) as at raytrace_opencl.c:147
+        const float inv = 1.f / (abac * abac - abab * acac);
+        const V3 ap = sub3(along(o, t, d), a);
+        const float ap_ab = dot3(ap, ab);
+        const float ap_ac = dot3(ap, ac);
+        l1 = (abac * ap_ac - acac * ap_ab) * inv;
+        l2 = (abac * ap_ab - abab * ap_ac) * inv;
+        hit = (0 <= l1 && 0 <= l2 && l1 + l2 <= 1.f);
+    }
+    return hit;
+}
+
+struct __attribute__((packed, aligned(4))) GridBlock { uint32_t lo, hi, rank; };
+
 } // namespace
 
 // ---- stage 1: primary rays ---------------------------------------------------------------------------------------
@@ -447,8 +477,9 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
             dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z);
         }
         wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-        word = S.gridBits[wordAt];
-        wordRank = S.gridRank[wordAt];
+        const GridBlock gb = reinterpret_cast<const GridBlock *>(S.gridBlock)[wordAt];
+        word = ((unsigned long long)gb.hi << 32) | gb.lo;
+        wordRank = gb.rank;
     }
 
     uint32_t budget = budgetPerRay;
@@ -457,11 +488,20 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
         const bool walking = active && budget != 0;
         if (walking && !pending) {
             const uint32_t bit = (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4));
+#ifdef RT_ABLATE_NO_SCAN
+            if (false) {
+#else
             if ((word >> bit) & 1ull) {
+#endif
                 // park, and fetch the cell's pair range now: it is in registers by the time the wave scans
                 const uint32_t k = wordRank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
-                first = S.cellFirst[k];
-                last = S.cellFirst[k + 1];
+#ifdef RT_ABLATE_RANGE0
+                const uint2 range = S.cellRange[k & 63u];
+#else
+                const uint2 range = S.cellRange[k];
+#endif
+                first = range.x;
+                last = range.y;
                 pending = true;
             }
         }
@@ -474,12 +514,14 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
             float tbest = tmax, bl1 = 0.f, bl2 = 0.f; // running maximum is reset per cell (:366)
             if (pending) {
                 for (uint32_t i = first; i < last; ++i) {
-                    const uint32_t tri = S.pairTri[i];
-                    if (excluded != tri) {
-                        float t, l1, l2;
-                        if (tri_test(S.pairRec, i, o, d, tmin, tbest, t, l1, l2)) {
-                            best = tri; tbest = t; bl1 = l1; bl2 = l2;
-                        }
+                    uint32_t tri;
+                    float t, l1, l2;
+#ifdef RT_ABLATE_REC0
+                    if (pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(i & 63u), o, d, tmin, tbest, excluded, tri, t, l1, l2)) {
+#else
+                    if (pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)i, o, d, tmin, tbest, excluded, tri, t, l1, l2)) {
+#endif
+                        best = tri; tbest = t; bl1 = l1; bl2 = l2;
                     }
                 }
                 pending = false;
@@ -499,11 +541,24 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
                 done = (c < 0) | (RT_GRID_DIV <= c);
                 if (!done) {
                     const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
+#ifdef RT_ABLATE_NO_DIV
+                    const float nd = (planes[axisBase + c + pos] - oo) * dd;
+#else
                     const float nd = (planes[axisBase + c + pos] - oo) / dd;
+#endif
                     cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
                     dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
                     const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-                    if (at != wordAt) { wordAt = at; word = S.gridBits[at]; wordRank = S.gridRank[at]; }
+#ifdef RT_ABLATE_NO_WORD
+                    if (false) {
+#else
+                    if (at != wordAt) {
+#endif
+                        wordAt = at;
+                        const GridBlock gb = reinterpret_cast<const GridBlock *>(S.gridBlock)[at];
+                        word = ((unsigned long long)gb.hi << 32) | gb.lo;
+                        wordRank = gb.rank;
+                    }
                 }
             }
             if (done) {
