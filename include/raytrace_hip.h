@@ -205,6 +205,9 @@ int rtHipSetPipeline(rtHipScene *scene, int pipeline);
 int rtHipStageTiming(rtHipScene *scene, int enable);
 int rtHipStageTimes(rtHipScene *scene, double ms[4], uint64_t *rounds);
 
+/* Diagnostic: copies the scene's 8 device-side debug counters (and optionally clears them).  Synchronous. */
+int rtHipDebugCounters(rtHipScene *scene, unsigned long long out[8], int clear);
+
 /* Same, with work counters (slower; never used inside a timed region).  Synchronous. */
 int rtHipRenderTilesCounted(rtHipScene *scene, rtHipStats *stats);
 

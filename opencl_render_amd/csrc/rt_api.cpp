@@ -529,6 +529,18 @@ int rtHipSetPipeline(rtHipScene *sc, int pipeline)
     return 0;
 }
 
+// Diagnostic: raw copy of the 8 device-side debug counters (work counters of the counted kernel, or the cycle sums of
+// an RT_DIAG_STAMPS build).  clear != 0 zeroes them afterwards.
+int rtHipDebugCounters(rtHipScene *sc, unsigned long long out[8], int clear)
+{
+    if (!sc || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(sc->device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out, sc->dev.stats, 64, hipMemcpyDeviceToHost));
+    if (clear) HIP_OK(hipMemset(sc->dev.stats, 0, 64));
+    return 0;
+}
+
 int rtHipStageTiming(rtHipScene *sc, int enable)
 {
     if (!sc) return fail("null scene");

@@ -63,16 +63,15 @@ __device__ __forceinline__ uint32_t camera_scan(const RtDevScene &S, uint32_t lo
 __device__ __forceinline__ bool pair_test(const float4 *__restrict__ rec, V3 o, V3 d, float tmin, float tmax, uint32_t excluded,
                                           uint32_t &tri, float &t, float &l1, float &l2)
 {
-    const float4 r0 = rec[0];
+    // all four quads are requested together: one round trip per candidate instead of two dependent ones
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
     tri = __float_as_uint(r0.w);
     if (tri == excluded) return false;
-    const float4 r1 = rec[1];
     const V3 a = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z);
     const V3 ao = sub3(o, a);
     t = -dot3(n, ao) / dot3(n, d);
     bool hit = false;
     if (tmin < t && t < tmax) {
-        const float4 r2 = rec[2], r3 = rec[3];
         const V3 ab = mk(r2.x, r2.y, r2.z), ac = mk(r3.x, r3.y, r3.z);
         const float abab = r2.w, abac = dot3(ab, ac), acac = r3.w; // dot(ab,ac) as at raytrace_opencl.c:147
         const float inv = 1.f / (abac * abac - abab * acac);
@@ -87,6 +86,16 @@ __device__ __forceinline__ bool pair_test(const float4 *__restrict__ rec, V3 o, 
 }
 
 struct __attribute__((packed, aligned(4))) GridBlock { uint32_t lo, hi, rank; };
+
+#ifdef RT_DIAG_STAMPS
+// Diagnostic build only (never shipped, outputs untouched): shader-clock stamps, summed per wave into S.stats.
+__device__ __forceinline__ unsigned long long diag_stamp()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#endif
 
 } // namespace
 
@@ -394,27 +403,37 @@ __global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const
 
 // ---- stage 3: grid traversal in resumable passes -----------------------------------------------------------------------
 // One queued ray per lane (raytrace_opencl.c:324-401); one workgroup per 256 queue entries, no fetch atomics.
-// Per iteration a lane visits ONE cell: occupancy bit from the cached 4x4x4 block word; a lane on an occupied cell parks
-// until enough lanes of its wave are parked, then they scan their cells' (contiguous) candidate records together;
-// end-cell test; branch-free step of the axis with the smallest plane distance (one IEEE divide).
+//
+// WALK, THEN TEST.  Where a ray walks does not depend on what it hits -- only where it stops does: the reference resets
+// its running maximum in every cell (:366) and ends at the first cell that produced any hit (:380).  So a lane walks
+// freely (one cell per iteration: occupancy bit from the cached 4x4x4 block word, end-cell test, branch-free step of the
+// axis with the smallest plane distance, one IEEE divide) and only RECORDS the dense ids of the occupied cells it passes
+// in a small per-lane list in LDS.  When lists fill up, or too few lanes are still walking, the wave tests: every lane
+// goes through its recorded cells in path order (next cell's range load in flight while the current cell's contiguous
+// candidate records are tested); the first cell with a hit ends the ray, and a ray without a hit carries on walking from
+// where it stands.  Walking iterations carry no long-latency loads and no divergent scan code, which is what made the
+// interleaved version slow (5,700 cycles per iteration, 28 of 64 lanes busy: profiles/r01_*).
+//
 // A ray gets `budget` cell visits per pass.  Rays still walking when it runs out are appended to the continuation
 // queue (one atomic per workgroup, aggregated through LDS) and resumed by the next pass re-packed into full waves.
-// Results do not depend on where a walk is cut: the continuation carries the exact DDA state (cell, end cell, the three
-// plane distances); the ray itself stays in the request arrays.
+// Results do not depend on where a walk is cut or tested: the continuation carries the exact DDA state.
 #ifndef RT_WF_TRACE_WAVES
-#define RT_WF_TRACE_WAVES 8
+#define RT_WF_TRACE_WAVES 6
 #endif
-#ifndef RT_WF_SCAN_MIN
-#define RT_WF_SCAN_MIN 24         // scan parked lanes once this many wait on an occupied cell ...
+#ifndef RT_WF_LIST
+#define RT_WF_LIST 8              // occupied cells a lane may record before it has to test them (LDS: 4 B x 256 each)
 #endif
-#ifndef RT_WF_STEP_MIN
-#define RT_WF_STEP_MIN 20         // ... or when fewer than this many lanes are still stepping
+#ifndef RT_WF_STALL_WEIGHT
+#define RT_WF_STALL_WEIGHT 1      // test once (lanes stalled on a full list) x weight exceeds the lanes still walking
 #endif
 template <bool FRESH>
 __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
                                                                          const uint32_t pass, const uint32_t budgetPerRay)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
+    __shared__ uint32_t cellList[RT_WF_LIST][256]; // [entry][thread]: conflict-free, 4 B apart across a wave
+    __shared__ uint8_t ownerOf[4][RT_WF_LIST * 64];  // per wave: which lane recorded flattened cell item c
+    __shared__ unsigned long long keyOf[4][64];      // per wave and lane: min over its hit cells of (cell order << 32 | pair index)
     __shared__ uint32_t spillWave[4], spillBase;
 
     const uint32_t slotId = round * RT_WF_PASSES + pass;
@@ -428,12 +447,13 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     const uint32_t in = round & 1;
     const uint4 *__restrict__ contIn = W.cont[(pass + 1) & 1];
     uint4 *__restrict__ contOut = W.cont[pass & 1];
+    const GridBlock *__restrict__ gridBlock = reinterpret_cast<const GridBlock *>(S.gridBlock);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
     const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
 
-    bool active = mine < total, pending = false;
-    uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0, first = 0, last = 0;
+    bool active = mine < total;
+    uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0;
     unsigned long long word = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
@@ -477,97 +497,166 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
             dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z);
         }
         wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-        const GridBlock gb = reinterpret_cast<const GridBlock *>(S.gridBlock)[wordAt];
+        const GridBlock gb = gridBlock[wordAt];
         word = ((unsigned long long)gb.hi << 32) | gb.lo;
         wordRank = gb.rank;
     }
 
     uint32_t budget = budgetPerRay;
+#ifdef RT_DIAG_STAMPS
+    unsigned long long dgWalk = 0, dgTest = 0, dgWalkIters = 0, dgBatches = 0, dgTestLanes = 0, dgCells = 0;
+    const unsigned long long dgStart = diag_stamp();
+#endif
+    uint32_t guard = 4096; // > 766 cell visits per walk (wave-uniform)
+    uint32_t listed = 0;   // occupied cells recorded and not yet tested
+    bool walkEnded = false; // the walk itself is over (end cell reached or the grid left): only recorded cells can still hit
+
 #pragma unroll 1
     for (;;) {
-        const bool walking = active && budget != 0;
-        if (walking && !pending) {
-            const uint32_t bit = (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4));
-#ifdef RT_ABLATE_NO_SCAN
-            if (false) {
-#else
-            if ((word >> bit) & 1ull) {
+        // ---- walk: no long-latency loads, no scan code ----------------------------------------------------------------
+#ifdef RT_DIAG_STAMPS
+        const unsigned long long dgW0 = diag_stamp();
 #endif
-                // park, and fetch the cell's pair range now: it is in registers by the time the wave scans
-                const uint32_t k = wordRank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
-#ifdef RT_ABLATE_RANGE0
-                const uint2 range = S.cellRange[k & 63u];
-#else
-                const uint2 range = S.cellRange[k];
+#pragma unroll 1
+        for (;;) {
+#ifdef RT_DIAG_STAMPS
+            dgWalkIters++;
 #endif
-                first = range.x;
-                last = range.y;
-                pending = true;
-            }
-        }
-        const int parked = __popcll(__ballot(walking && pending));
-        const int moving = __popcll(__ballot(walking && !pending));
-        if (parked + moving == 0) break;
-        const bool scanNow = parked >= RT_WF_SCAN_MIN || moving < RT_WF_STEP_MIN;
-        if (walking && (!pending || scanNow)) {
-            uint32_t best = RT_NONE;
-            float tbest = tmax, bl1 = 0.f, bl2 = 0.f; // running maximum is reset per cell (:366)
-            if (pending) {
-                for (uint32_t i = first; i < last; ++i) {
-                    uint32_t tri;
-                    float t, l1, l2;
-#ifdef RT_ABLATE_REC0
-                    if (pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(i & 63u), o, d, tmin, tbest, excluded, tri, t, l1, l2)) {
-#else
-                    if (pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)i, o, d, tmin, tbest, excluded, tri, t, l1, l2)) {
-#endif
-                        best = tri; tbest = t; bl1 = l1; bl2 = l2;
-                    }
+            const bool canWalk = active && !walkEnded && budget != 0 && listed < RT_WF_LIST;
+            const unsigned long long walkers = __ballot(canWalk);
+            // A test batch costs a chain of dependent gathers whatever the number of lanes in it, a walking iteration is
+            // cheap: walk until nobody can, or until the lanes stalled on a full list outnumber the walkers.
+            if (walkers == 0ull) break;
+            const int stalled = __popcll(__ballot(active && !walkEnded && budget != 0 && listed >= RT_WF_LIST));
+            if (stalled * RT_WF_STALL_WEIGHT > __popcll(walkers)) break;
+            if (--guard == 0) break; // cannot happen (every iteration spends budget); keeps a logic error from hanging the GPU
+            if (canWalk) {
+                const uint32_t bit = (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4));
+                if ((word >> bit) & 1ull) {
+                    cellList[listed][threadIdx.x] = wordRank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull)); // dense cell id
+                    ++listed;
                 }
-                pending = false;
-            }
-            --budget;
-            // first cell with a hit ends the walk, as does the end cell (:380-381)
-            bool done = (best != RT_NONE) || (cx == ex && cy == ey && cz == ez);
-            if (!done) {
-                // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
-                const bool sxm = (dx < dy) & (dx < dz);
-                const bool sym = !sxm & (dy < dz);
-                const float dd = sxm ? d.x : (sym ? d.y : d.z);
-                const float oo = sxm ? o.x : (sym ? o.y : o.z);
-                int c = sxm ? cx : (sym ? cy : cz);
-                const int pos = (0 <= dd) ? 1 : 0;
-                c += pos ? 1 : -1;
-                done = (c < 0) | (RT_GRID_DIV <= c);
+                --budget;
+                // the end cell ends the walk after it has been visited (:380-381)
+                bool done = (cx == ex && cy == ey && cz == ez);
                 if (!done) {
-                    const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
-#ifdef RT_ABLATE_NO_DIV
-                    const float nd = (planes[axisBase + c + pos] - oo) * dd;
-#else
-                    const float nd = (planes[axisBase + c + pos] - oo) / dd;
+                    // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
+                    const bool sxm = (dx < dy) & (dx < dz);
+                    const bool sym = !sxm & (dy < dz);
+                    const float dd = sxm ? d.x : (sym ? d.y : d.z);
+                    const float oo = sxm ? o.x : (sym ? o.y : o.z);
+                    int c = sxm ? cx : (sym ? cy : cz);
+                    const int pos = (0 <= dd) ? 1 : 0;
+                    c += pos ? 1 : -1;
+                    done = (c < 0) | (RT_GRID_DIV <= c);
+                    if (!done) {
+                        const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
+                        const float nd = (planes[axisBase + c + pos] - oo) / dd;
+                        cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
+                        dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
+                        const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+                        if (at != wordAt) {
+                            wordAt = at;
+                            const GridBlock gb = gridBlock[at];
+                            word = ((unsigned long long)gb.hi << 32) | gb.lo;
+                            wordRank = gb.rank;
+                        }
+                    }
+                }
+                walkEnded = done;
+            }
+        }
+
+#ifdef RT_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long dgT0 = diag_stamp();
+        dgWalk += dgT0 - dgW0;
+        dgBatches++;
+        dgTestLanes += (unsigned long long)__popcll(__ballot(active && listed));
 #endif
-                    cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
-                    dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
-                    const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-#ifdef RT_ABLATE_NO_WORD
-                    if (false) {
-#else
-                    if (at != wordAt) {
+        // ---- test, wave-cooperative: the wave's recorded cells are flattened into items and every lane takes one cell
+        // per round, whoever recorded it (ray data comes from the owner lane by ds_bpermute).  A cell's candidates are
+        // tested with the reference's running maximum (:366-379); the owner's answer is the hit of its EARLIEST cell
+        // (:380), found with an LDS atomicMin on (cell order, pair index); the owner then re-evaluates that one pair,
+        // which reproduces t, l1, l2 bit for bit.
+        {
+            const uint32_t mineN = active ? listed : 0u;
+            uint32_t incl = mineN;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if ((int)lane >= off) incl += up;
+            }
+            const uint32_t myBase = incl - mineN;
+            const uint32_t items = __shfl(incl, 63, 64);
+#ifdef RT_DIAG_STAMPS
+            dgCells += items;
 #endif
-                        wordAt = at;
-                        const GridBlock gb = reinterpret_cast<const GridBlock *>(S.gridBlock)[at];
-                        word = ((unsigned long long)gb.hi << 32) | gb.lo;
-                        wordRank = gb.rank;
+            if (items) { // wave-uniform
+                volatile uint8_t *owners = ownerOf[wave];
+                volatile unsigned long long *keys = keyOf[wave];
+                for (uint32_t j = 0; j < mineN; ++j) owners[myBase + j] = (uint8_t)lane;
+                keys[lane] = ~0ull;
+                __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
+                for (uint32_t c0 = 0; c0 < items; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    const bool has = c < items;
+                    const uint32_t owner = has ? owners[c] : 0u;
+                    // the owner's ray (all lanes take part in the permutes)
+                    const uint32_t ownerBase = __shfl(myBase, owner, 64);
+                    const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+                    const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+                    const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64);
+                    const uint32_t pexcl = __shfl(excluded, owner, 64);
+                    if (has) {
+                        const uint32_t j = c - ownerBase;
+                        const uint2 range = S.cellRange[cellList[j][(wave << 6) + owner]];
+                        uint32_t bestPair = RT_NONE;
+                        float tbest = ptmax; // running maximum, reset per cell (:366)
+                        for (uint32_t i = range.x; i < range.y; ++i) {
+                            uint32_t tri;
+                            float t, l1, l2;
+                            if (pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)i, po, pd, ptmin, tbest, pexcl, tri, t, l1, l2)) {
+                                bestPair = i; tbest = t;
+                            }
+                        }
+                        if (bestPair != RT_NONE)
+                            atomicMin((unsigned long long *)&keys[owner], ((unsigned long long)j << 32) | (unsigned long long)bestPair);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mineN) {
+                    const unsigned long long key = keys[lane];
+                    if (key != ~0ull) {
+                        uint32_t tri;
+                        float t, l1, l2;
+                        pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key, o, d, tmin, tmax, excluded, tri, t, l1, l2);
+                        W.res[q] = make_uint4(tri, __float_as_uint(t), __float_as_uint(l1), __float_as_uint(l2));
+                        active = false;
                     }
                 }
             }
-            if (done) {
-                W.res[q] = make_uint4(best, __float_as_uint(tbest), __float_as_uint(bl1), __float_as_uint(bl2));
-                active = false;
-            }
+            listed = 0;
         }
+#ifdef RT_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dgTest += diag_stamp() - dgT0;
+#endif
+        if (active && walkEnded) { // walked to the end without a hit
+            W.res[q] = make_uint4(RT_NONE, __float_as_uint(tmax), 0u, 0u);
+            active = false;
+        }
+        // anything left to walk in this pass?
+        if (__ballot(active && budget != 0) == 0ull || guard == 0) break;
     }
 
+#ifdef RT_DIAG_STAMPS
+    if (lane == 0) {
+        atomicAdd(&S.stats[0], diag_stamp() - dgStart); atomicAdd(&S.stats[1], dgWalk); atomicAdd(&S.stats[2], dgTest);
+        atomicAdd(&S.stats[3], dgWalkIters); atomicAdd(&S.stats[4], dgBatches); atomicAdd(&S.stats[5], dgTestLanes);
+        atomicAdd(&S.stats[6], 1ull); atomicAdd(&S.stats[7], dgCells);
+    }
+#endif
     // rays that are still walking leave through the continuation queue: one atomic per workgroup
     const unsigned long long spillMask = __ballot(active);
     if (lane == 0) spillWave[wave] = (uint32_t)__popcll(spillMask);

@@ -63,7 +63,7 @@ DROPIN_SYMBOLS = [
 ]
 RESIDENT_SYMBOLS = [
     "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles",
-    "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes",
+    "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildSceneGrid", "rtHipFree",
 ]
@@ -121,6 +121,7 @@ def lib() -> C.CDLL:
     L.rtHipSceneBytes.argtypes = [vp]
     L.rtHipRenderTiles.argtypes = [vp, vp]
     L.rtHipRenderTilesCounted.argtypes = [vp, C.POINTER(Stats)]
+    L.rtHipDebugCounters.argtypes = [vp, C.POINTER(C.c_uint64 * 8), C.c_int]
     L.rtHipSetPipeline.argtypes = [vp, C.c_int]
     L.rtHipStageTiming.argtypes = [vp, C.c_int]
     L.rtHipStageTimes.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
@@ -314,6 +315,11 @@ class ResidentScene:
         ms, rounds = (C.c_double * 4)(), C.c_uint64()
         self._check(lib().rtHipStageTimes(self.handle, C.byref(ms), C.byref(rounds)), "rtHipStageTimes")
         return dict(primary=ms[0], logic=ms[1], trace=ms[2], accum=ms[3]), rounds.value
+
+    def debug_counters(self, clear: bool = True):
+        out = (C.c_uint64 * 8)()
+        self._check(lib().rtHipDebugCounters(self.handle, C.byref(out), 1 if clear else 0), "rtHipDebugCounters")
+        return [int(v) for v in out]
 
     def render_counted(self) -> dict:
         st = Stats()
