@@ -73,7 +73,7 @@ struct rtHipScene {
     int pipeline = RT_HIP_PIPELINE_WAVEFRONT;
     RtWavefront wf{};
     uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
-    uint32_t passCount = 4, passBudget[RT_WF_PASSES] = { 64, 128, 256, 0xffffffffu };
+    uint32_t passCount = 2, passBudget[RT_WF_PASSES] = { 128, 0xffffffffu }; // measured best on the headline scene
     uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum]
     struct StageEvent { int stage; hipEvent_t a, b; };
@@ -359,11 +359,15 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
         if (sb > d->sampleCount) sb = d->sampleCount;
-        if (pix * sb > 0xfffffff0ull) return fail("tile set too large for one batch");
         sc->samplesPerBatch = (uint32_t)sb;
-        const uint64_t cap = pix * sb;
+        // queue slices: the primary kernel's workgroups are dealt to the shards round-robin, 256 paths each at most
+        const uint64_t primaryBlocks = (uint64_t)nt * 64 * sb;
+        const uint64_t shardCap = ((primaryBlocks + RT_WF_SHARDS - 1) / RT_WF_SHARDS) * 256;
+        const uint64_t cap = shardCap * RT_WF_SHARDS;
+        if (cap > 0xfffffff0ull) return fail("tile set too large for one batch");
         RtWavefront &Wf = sc->wf;
         Wf.capacity = (uint32_t)cap;
+        Wf.shardCap = (uint32_t)shardCap;
         Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
         if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
             sc->alloc<float4>(cap, &Wf.cur0) || sc->alloc<float4>(cap, &Wf.cur1) || sc->alloc<float4>(cap, &Wf.cur2) ||
@@ -373,15 +377,14 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             sc->alloc<float4>(cap, &Wf.shLum) || sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) ||
             sc->alloc<float4>(cap, &Wf.reqO[0]) || sc->alloc<float4>(cap, &Wf.reqO[1]) || sc->alloc<float4>(cap, &Wf.reqD[0]) ||
             sc->alloc<float4>(cap, &Wf.reqD[1]) || sc->alloc<uint2>(cap, &Wf.reqX[0]) || sc->alloc<uint2>(cap, &Wf.reqX[1]) ||
-            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(cap, &Wf.sampleOut) ||
+            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(pix * sb, &Wf.sampleOut) ||
             sc->alloc<uint4>(cap * 2, &Wf.cont[0]) || sc->alloc<uint4>(cap * 2, &Wf.cont[1]) ||
-            sc->alloc<uint32_t>((uint64_t)(RT_WF_MAX_ROUNDS + 2) * (1 + 2 * RT_WF_PASSES), &Wf.counts))
+            sc->alloc<uint32_t>((uint64_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, &Wf.counts))
             return -1;
-        Wf.cursors = Wf.counts + (RT_WF_MAX_ROUNDS + 2);
-        Wf.contCounts = Wf.cursors + (size_t)(RT_WF_MAX_ROUNDS + 2) * RT_WF_PASSES;
-        HIP_OK(hipHostMalloc((void **)&sc->hostCount, 64, hipHostMallocDefault));
+        Wf.contCounts = Wf.counts + 3 * RT_WF_SHARDS;
+        HIP_OK(hipHostMalloc((void **)&sc->hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        sc->traceBlocks = (uint32_t)((cap + 255) / 256);  // one workgroup per 256 queue entries; surplus groups exit at once
+        sc->traceBlocks = (uint32_t)(cap / 256);  // one workgroup per 256 entries of every slice; surplus groups exit at once
         (void)cus;
         sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
         if (sc->logicBlocks == 0) sc->logicBlocks = 1;
@@ -432,7 +435,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
     for (uint32_t base = 0; base < D.sampleCount; base += sc->samplesPerBatch) {
         Wf.sampleBase = base;
         Wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, D.sampleCount - base);
-        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * (size_t)(RT_WF_MAX_ROUNDS + 2) * (1 + 2 * RT_WF_PASSES), st));
+        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * (size_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, st));
         HIP_OK(stage(0, [&] { return rtw_launch_primary(&D, &Wf, st); }));
         uint32_t r = 0;
         for (;;) {
@@ -443,9 +446,11 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
                 for (uint32_t p = 0; p < sc->passCount; ++p)
                     HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, p, sc->passBudget[p], sc->traceBlocks, st); }));
             }
-            HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + r, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + (r % 3) * RT_WF_SHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
-            if (*sc->hostCount == 0) break;
+            uint64_t waiting = 0;
+            for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += sc->hostCount[i];
+            if (waiting == 0) break;
             if (r >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
         }
         rounds += r;

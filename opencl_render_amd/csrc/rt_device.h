@@ -78,7 +78,8 @@ struct RtDevScene {
 // to a request queue; a persistent trace kernel consumes the queue with every lane busy (idle lanes refill from it).
 //   round r:   logic(r)  reads  req[r&1].path + res[q]   for q < counts[r]      -> appends to req[(r+1)&1], counts[r+1]
 //              trace(r+1) reads req[(r+1)&1][q]           for q < counts[r+1]    -> writes res[q]
-#define RT_WF_MAX_ROUNDS 4094
+#define RT_WF_MAX_ROUNDS 100000
+#define RT_WF_SHARDS 256      // every queue is cut into this many independent slices, each with its own counter
 #define RT_WF_PASSES 8        // at most this many trace passes per round; the last one runs every ray to its end
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
@@ -96,13 +97,14 @@ struct RtWavefront {
     float4 *reqO[2], *reqD[2]; // o.xyz,tmin | d.xyz,tmax
     uint2 *reqX[2];            // excluded triangle, path id
     uint4 *res;                // hit triangle (0xffffffff = none), t, l1, l2 (float bits)
-    uint32_t *counts;          // [RT_WF_MAX_ROUNDS+2] queue length per round (zeroed per batch)
-    // Grid walks are resumable: a trace PASS gives every ray a bounded number of cell steps; rays still walking are
-    // written to a continuation queue (DDA state only, the ray itself stays in req*) and the next pass runs them
-    // re-packed into full waves.  Per (round, pass): cursors = fetch cursor over the pass's input queue,
-    // contCounts = entries the pass appended to its output queue.
-    uint32_t *cursors;         // (unused by the workgroup-per-chunk trace kernel; kept zeroed)
-    uint32_t *contCounts;      // [(RT_WF_MAX_ROUNDS+2) * RT_WF_PASSES]
+    // Queues are SHARDED: a path is born into shard (primary workgroup % RT_WF_SHARDS) and everything it ever emits --
+    // ray requests, continuation entries -- goes to the same shard's slice [shard*shardCap, (shard+1)*shardCap) of the
+    // queue arrays.  Appends therefore hit RT_WF_SHARDS different counters instead of one (a single address sustains
+    // only ~90 atomics/us, which was the whole cost of the primary and logic kernels), and a slice can never overflow:
+    // it holds at most the paths born into it.  Counters are small rings zeroed in-stream by the logic kernel.
+    uint32_t shardCap;         // entries per shard (multiple of 256); arrays hold RT_WF_SHARDS*shardCap entries
+    uint32_t *counts;          // [3][RT_WF_SHARDS] fresh-request queue length; round r reads [r%3], appends to [(r+1)%3]
+    uint32_t *contCounts;      // [RT_WF_PASSES][RT_WF_SHARDS] continuation entries appended by each trace pass
     uint4 *cont[2];            // [capacity][2]: {q, cx|cy<<8|cz<<16, ex|ey<<8|ez<<16|hasEnd<<24, -} {dx, dy, dz, -}
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
         if (hit_tri == RT_NONE) W.sampleOut[outSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const bool born = valid && hit_tri != RT_NONE;
-    const uint32_t a = wave_append(&W.counts[0], born);
+    // workgroups are dealt to the shards round-robin: concurrently running groups append to different counters
+    const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) % RT_WF_SHARDS;
+    const uint32_t a = shard * W.shardCap + wave_append(&W.counts[shard], born); // round 0 uses ring slot 0
     if (born) {
         W.rng[a] = rng;
         W.meta[a] = make_uint4(outSlot, localPixel, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), hit_tri);
@@ -152,15 +154,27 @@ __global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
     __syncthreads();
 
-    const uint32_t total = W.counts[round];
     const uint32_t in = round & 1, outq = in ^ 1;
+    const uint32_t *countIn = W.counts + (round % 3) * RT_WF_SHARDS;
+    uint32_t *countOut = W.counts + ((round + 1) % 3) * RT_WF_SHARDS;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t waveId = (blockIdx.x * 256 + threadIdx.x) >> 6, waves = (gridDim.x * 256) >> 6;
     Counters cn; // unused (COUNT=false instantiations below)
+    // in-stream housekeeping: the ring slot two rounds ahead and the continuation counters of the coming trace passes
+    {
+        const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+        if (gid < RT_WF_SHARDS) W.counts[((round + 2) % 3) * RT_WF_SHARDS + gid] = 0u;
+        if (gid < RT_WF_PASSES * RT_WF_SHARDS) W.contCounts[gid] = 0u;
+    }
 
-    for (uint32_t base = waveId * 64; base < total; base += waves * 64) {
-        const uint32_t q = base + lane;
-        const bool live = q < total;
+    const uint32_t chunksPerShard = W.shardCap >> 6;
+    for (uint32_t chunk = waveId; chunk < RT_WF_SHARDS * chunksPerShard; chunk += waves) {
+        const uint32_t shard = chunk / chunksPerShard;
+        const uint32_t total = countIn[shard];
+        const uint32_t local = (chunk - shard * chunksPerShard) * 64 + lane;
+        if ((chunk - shard * chunksPerShard) * 64 >= total) continue; // wave-uniform
+        const uint32_t q = shard * W.shardCap + local;
+        const bool live = local < total;
         bool emit = false;
         V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
         float rtmin = 0.f, rtmax = 0.f;
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const
             }
         }
         // every lane of the wave arrives here: one atomic per wave for the rays of the next round
-        const uint32_t slot = wave_append(&W.counts[round + 1], emit);
+        const uint32_t slot = shard * W.shardCap + wave_append(&countOut[shard], emit);
         if (emit) {
             W.reqO[outq][slot] = pack4(ro, rtmin);
             W.reqD[outq][slot] = pack4(rd, rtmax);
@@ -436,11 +450,15 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     __shared__ unsigned long long keyOf[4][64];      // per wave and lane: min over its hit cells of (cell order << 32 | pair index)
     __shared__ uint32_t spillWave[4], spillBase;
 
-    const uint32_t slotId = round * RT_WF_PASSES + pass;
+    // one workgroup per 256 entries of one shard's slice
+    const uint32_t blocksPerShard = W.shardCap >> 8;
+    const uint32_t shard = blockIdx.x / blocksPerShard;
+    const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
     // input: the round's fresh requests (pass 0) or what the previous pass spilled
-    const uint32_t total = FRESH ? W.counts[round] : W.contCounts[slotId - 1];
-    const uint32_t mine = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= total) return; // whole workgroup beyond the queue
+    const uint32_t total = FRESH ? W.counts[(round % 3) * RT_WF_SHARDS + shard] : W.contCounts[(pass - 1) * RT_WF_SHARDS + shard];
+    if (local0 >= total) return; // whole workgroup beyond the slice's entries
+    const uint32_t localIdx = local0 + threadIdx.x;
+    const uint32_t mine = shard * W.shardCap + localIdx;
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
     const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
 
-    bool active = mine < total;
+    bool active = localIdx < total;
     uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0;
     unsigned long long word = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
@@ -663,7 +681,7 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t n = spillWave[0] + spillWave[1] + spillWave[2] + spillWave[3];
-        spillBase = n ? atomicAdd(&W.contCounts[slotId], n) : 0u;
+        spillBase = shard * W.shardCap + (n ? atomicAdd(&W.contCounts[pass * RT_WF_SHARDS + shard], n) : 0u);
     }
     __syncthreads();
     if (active) {
