@@ -86,11 +86,19 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available() or R.lib().rtHipDeviceCount() < 1:
         sys.exit("bench.py: no HIP device visible -- the HIP path has no CPU fallback")
+    # RT_BENCH_REHEARSE=1: functional rehearsal of the N>1 path on ONE GPU -- every rank uses device 0 and the
+    # collectives run on gloo through host memory.  Timings of such a run mean nothing; results must still be exact.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- scene: built once on rank 0, shipped to the other ranks over RCCL -----------------------------------------
     sc = None
@@ -149,7 +157,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = rs.kernel_time_ms()
@@ -171,7 +179,7 @@ def main():
     total_stats = dict(stats)
     if world > 1:
         keys = sorted(stats)
-        t = torch.tensor([stats[k] for k in keys], dtype=torch.int64, device=device)
+        t = torch.tensor([stats[k] for k in keys], dtype=torch.int64, device="cpu" if rehearse else device)
         dist.all_reduce(t)
         total_stats = {k: int(v) for k, v in zip(keys, t.tolist())}
 
@@ -221,6 +229,16 @@ def main():
             "t_host_prep_s": {"camera_lists": round(sc.meta.get("t_cam_list_s", 0), 3), "grid": round(sc.meta.get("t_grid_s", 0), 3)},
         }
         # ---- CPU baseline + parity gate (rank 0, N=1 only): the oracle on a bounded sample of the same frame ------
+        if world > 1 and rehearse:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O  # checker only
+            bad = 0
+            rows = list(range(0, H, 97))
+            for y in rows:
+                want = O.oracle_render(sc, threads=os.cpu_count() or 1, first_pixel=y * W, pixel_count=W)
+                for c in range(3):
+                    bad += int((want[c][y] != got[c, y]).sum())
+            out["parity"] = {"rows_checked": len(rows), "mismatching_values": bad, "bar": "bit-exact u16 planes vs CPU oracle (rehearsal)"}
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O  # checker only: never part of the measured path

@@ -42,6 +42,15 @@ def gather_tiles(local: torch.Tensor, width: int, height: int, rank: int, world:
         send[: local.numel()] = local
     if world == 1:
         return send.view(1, cap)
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
+        host = send.cpu()
+        if rank == 0:
+            out = torch.empty((world, cap), dtype=torch.uint8)
+            dist.gather(host, list(out.unbind(0)), dst=0, group=group)
+            return out.to(local.device)
+        dist.gather(host, None, dst=0, group=group)
+        return None
     if rank == 0:
         out = torch.empty((world, cap), dtype=torch.uint8, device=local.device)
         dist.gather(send, list(out.unbind(0)), dst=0, group=group)
@@ -87,6 +96,8 @@ def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=
     for k in _ARRAY_FIELDS:
         shape, dtype = layout[k]
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if dist.get_backend(group) == "gloo":
+            device = torch.device("cpu")  # rehearsal mode: plain host broadcast
         if rank == 0:
             src = np.ascontiguousarray(getattr(sc, k))
             t = torch.from_numpy(src.view(np.uint8).reshape(-1).copy()).to(device)
