@@ -354,7 +354,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, sc->device));
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16 + 2 * 32;
+        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16 + 2 * 64;
         const uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
@@ -378,7 +378,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             sc->alloc<float4>(cap, &Wf.reqO[0]) || sc->alloc<float4>(cap, &Wf.reqO[1]) || sc->alloc<float4>(cap, &Wf.reqD[0]) ||
             sc->alloc<float4>(cap, &Wf.reqD[1]) || sc->alloc<uint2>(cap, &Wf.reqX[0]) || sc->alloc<uint2>(cap, &Wf.reqX[1]) ||
             sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(pix * sb, &Wf.sampleOut) ||
-            sc->alloc<uint4>(cap * 2, &Wf.cont[0]) || sc->alloc<uint4>(cap * 2, &Wf.cont[1]) ||
+            sc->alloc<uint4>(cap * 4, &Wf.cont[0]) || sc->alloc<uint4>(cap * 4, &Wf.cont[1]) ||
             sc->alloc<uint32_t>((uint64_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, &Wf.counts))
             return -1;
         Wf.contCounts = Wf.counts + 3 * RT_WF_SHARDS;

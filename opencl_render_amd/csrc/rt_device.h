@@ -105,7 +105,7 @@ struct RtWavefront {
     uint32_t shardCap;         // entries per shard (multiple of 256); arrays hold RT_WF_SHARDS*shardCap entries
     uint32_t *counts;          // [3][RT_WF_SHARDS] fresh-request queue length; round r reads [r%3], appends to [(r+1)%3]
     uint32_t *contCounts;      // [RT_WF_PASSES][RT_WF_SHARDS] continuation entries appended by each trace pass
-    uint4 *cont[2];            // [capacity][2]: {q, cx|cy<<8|cz<<16, ex|ey<<8|ez<<16|hasEnd<<24, -} {dx, dy, dz, -}
+    uint4 *cont[2];            // [capacity][4], self-contained: {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz,-}
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 }
 
 // ---- stage 2: per-path state machine ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+#ifndef RT_WF_LOGIC_WAVES
+#define RT_WF_LOGIC_WAVES 2
+#endif
+__global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
 {
     __shared__ Shared sh; // only the texel/255 table is used here
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
@@ -437,6 +440,9 @@ __global__ __launch_bounds__(256) void wf_logic_kernel(const RtDevScene S, const
 #ifndef RT_WF_LIST
 #define RT_WF_LIST 8              // occupied cells a lane may record before it has to test them (LDS: 4 B x 256 each)
 #endif
+#ifndef RT_WF_UNROLL
+#define RT_WF_UNROLL 4            // cell visits between two checks of the wave's walk/test decision
+#endif
 #ifndef RT_WF_STALL_WEIGHT
 #define RT_WF_STALL_WEIGHT 1      // test once (lanes stalled on a full list) x weight exceeds the lanes still walking
 #endif
@@ -471,21 +477,20 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
 
     bool active = localIdx < total;
-    uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0;
-    unsigned long long word = 0;
+    uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0, wordLo = 0, wordHi = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    int cx = 0, cy = 0, cz = 0, ex = -1, ey = -1, ez = -1;
+    uint32_t cell = 0;             // cx | cy << 8 | cz << 16
+    uint32_t endCell = 0xffffffffu; // same packing; all ones = the ray has no end cell (tmax infinite)
 
     if (active) {
-        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
-        if (FRESH) q = mine;
-        else { c0 = contIn[2 * (size_t)mine]; c1 = contIn[2 * (size_t)mine + 1]; q = c0.x; }
-        const float4 ro = W.reqO[in][q], rd = W.reqD[in][q];
-        o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
-        excluded = W.reqX[in][q].x;
         if (FRESH) {
+            q = mine;
+            const float4 ro = W.reqO[in][q], rd = W.reqD[in][q];
+            o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
+            excluded = W.reqX[in][q].x;
             // start / end cells (:351-362)
+            int cx = 0, cy = 0, cz = 0;
             V3 from = along(o, tmin, d);
             bind_in_cube(from, d, lo, hi);
 #pragma unroll
@@ -494,30 +499,35 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
                 if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
                 if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
             }
+            cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
             if (tmax < RT_INF) {
                 V3 to = along(o, tmax, d);
                 bind_in_cube(to, d, lo, hi);
-                ex = 0; ey = 0; ez = 0;
+                int ex = 0, ey = 0, ez = 0;
 #pragma unroll
                 for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
                     if (planes[ex + div] < to.x) ex += div;
                     if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
                     if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
                 }
+                endCell = (uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16);
             }
             // distances from the ray ORIGIN to the next plane of each axis (:383-385)
             dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
             dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
             dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
         } else {
-            cx = (int)(c0.y & 255u); cy = (int)((c0.y >> 8) & 255u); cz = (int)((c0.y >> 16) & 255u);
-            if (c0.z >> 24) { ex = (int)(c0.z & 255u); ey = (int)((c0.z >> 8) & 255u); ez = (int)((c0.z >> 16) & 255u); }
-            dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z);
+            // a continuation entry is self-contained (64 B, read in queue order): no gather back into the request arrays
+            const uint4 c0 = contIn[4 * (size_t)mine], c1 = contIn[4 * (size_t)mine + 1];
+            const uint4 c2 = contIn[4 * (size_t)mine + 2], c3 = contIn[4 * (size_t)mine + 3];
+            q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
+            dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
+            o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
+            d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
         }
-        wordAt = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
+        wordAt = ((cell >> 2) & 63u) | ((cell >> 4) & 0xFC0u) | ((cell >> 6) & 0x3F000u);
         const GridBlock gb = gridBlock[wordAt];
-        word = ((unsigned long long)gb.hi << 32) | gb.lo;
-        wordRank = gb.rank;
+        wordLo = gb.lo; wordHi = gb.hi; wordRank = gb.rank;
     }
 
     uint32_t budget = budgetPerRay;
@@ -548,40 +558,47 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
             const int stalled = __popcll(__ballot(active && !walkEnded && budget != 0 && listed >= RT_WF_LIST));
             if (stalled * RT_WF_STALL_WEIGHT > __popcll(walkers)) break;
             if (--guard == 0) break; // cannot happen (every iteration spends budget); keeps a logic error from hanging the GPU
-            if (canWalk) {
-                const uint32_t bit = (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4));
-                if ((word >> bit) & 1ull) {
-                    cellList[listed][threadIdx.x] = wordRank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull)); // dense cell id
-                    ++listed;
-                }
-                --budget;
-                // the end cell ends the walk after it has been visited (:380-381)
-                bool done = (cx == ex && cy == ey && cz == ez);
-                if (!done) {
-                    // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
-                    const bool sxm = (dx < dy) & (dx < dz);
-                    const bool sym = !sxm & (dy < dz);
-                    const float dd = sxm ? d.x : (sym ? d.y : d.z);
-                    const float oo = sxm ? o.x : (sym ? o.y : o.z);
-                    int c = sxm ? cx : (sym ? cy : cz);
-                    const int pos = (0 <= dd) ? 1 : 0;
-                    c += pos ? 1 : -1;
-                    done = (c < 0) | (RT_GRID_DIV <= c);
+#pragma unroll
+            for (int u = 0; u < RT_WF_UNROLL; ++u) { // the checks above are re-done every RT_WF_UNROLL cell visits
+                if (active && !walkEnded && budget != 0 && listed < RT_WF_LIST) {
+                    // occupancy bit of this cell in its 4x4x4 block word
+                    const uint32_t bit = (cell & 3u) | ((cell >> 6) & 12u) | ((cell >> 12) & 48u);
+                    const uint32_t half = (bit & 32u) ? wordHi : wordLo;
+                    if ((half >> (bit & 31u)) & 1u) {
+                        const uint32_t below = (bit & 32u) ? (uint32_t)__popc(wordLo) + (uint32_t)__popc(wordHi & ((1u << (bit & 31u)) - 1u))
+                                                           : (uint32_t)__popc(wordLo & ((1u << bit) - 1u));
+                        cellList[listed][threadIdx.x] = wordRank + below; // dense cell id
+                        ++listed;
+                    }
+                    --budget;
+                    // the end cell ends the walk after it has been visited (:380-381)
+                    bool done = (cell == endCell);
                     if (!done) {
-                        const int axisBase = sxm ? 0 : (sym ? (RT_GRID_DIV + 1) : 2 * (RT_GRID_DIV + 1));
-                        const float nd = (planes[axisBase + c + pos] - oo) / dd;
-                        cx = sxm ? c : cx; cy = sym ? c : cy; cz = (sxm | sym) ? cz : c;
-                        dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
-                        const uint32_t at = (uint32_t)((cx >> 2) + 64 * (cy >> 2) + 4096 * (cz >> 2));
-                        if (at != wordAt) {
-                            wordAt = at;
-                            const GridBlock gb = gridBlock[at];
-                            word = ((unsigned long long)gb.hi << 32) | gb.lo;
-                            wordRank = gb.rank;
+                        // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
+                        const bool sxm = (dx < dy) & (dx < dz);
+                        const bool sym = !sxm & (dy < dz);
+                        const float dd = sxm ? d.x : (sym ? d.y : d.z);
+                        const float oo = sxm ? o.x : (sym ? o.y : o.z);
+                        const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);
+                        const uint32_t c = (cell >> shift) & 255u;
+                        const bool pos = (0.f <= dd);
+                        done = pos ? (c == RT_GRID_DIV - 1) : (c == 0u); // the step would leave the grid (:389,:393,:397)
+                        if (!done) {
+                            const uint32_t axisBase = sxm ? 0u : (sym ? (uint32_t)(RT_GRID_DIV + 1) : (uint32_t)(2 * (RT_GRID_DIV + 1)));
+                            // plane index of the NEW cell: c+1+1 going up, c-1+0 going down
+                            const float nd = (planes[axisBase + (pos ? c + 2u : c - 1u)] - oo) / dd;
+                            cell = pos ? cell + (1u << shift) : cell - (1u << shift);
+                            dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
+                            const uint32_t at = ((cell >> 2) & 63u) | ((cell >> 4) & 0xFC0u) | ((cell >> 6) & 0x3F000u);
+                            if (at != wordAt) {
+                                wordAt = at;
+                                const GridBlock gb = gridBlock[at];
+                                wordLo = gb.lo; wordHi = gb.hi; wordRank = gb.rank;
+                            }
                         }
                     }
+                    walkEnded = done;
                 }
-                walkEnded = done;
             }
         }
 
@@ -687,9 +704,10 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     if (active) {
         uint32_t at = spillBase + (uint32_t)__popcll(spillMask & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < wave; ++w) at += spillWave[w];
-        const uint32_t endBits = (ex < 0) ? 0u : ((uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16) | (1u << 24));
-        contOut[2 * (size_t)at + 0] = make_uint4(q, (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16), endBits, 0u);
-        contOut[2 * (size_t)at + 1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), 0u);
+        contOut[4 * (size_t)at + 0] = make_uint4(q, cell, endCell, excluded);
+        contOut[4 * (size_t)at + 1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(tmin));
+        contOut[4 * (size_t)at + 2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+        contOut[4 * (size_t)at + 3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
     }
 }
 
