@@ -73,7 +73,7 @@ struct rtHipScene {
     int pipeline = RT_HIP_PIPELINE_WAVEFRONT;
     RtWavefront wf{};
     uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
-    uint32_t passCount = 2, passBudget[RT_WF_PASSES] = { 128, 0xffffffffu }; // measured best on the headline scene
+    uint32_t passCount = 1, passBudget[RT_WF_PASSES] = { 0xffffffffu }; // one unbounded pass measured best (1080p and 4K)
     uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum]
     struct StageEvent { int stage; hipEvent_t a, b; };
@@ -394,7 +394,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 char *endp = nullptr;
                 const unsigned long v = strtoul(b, &endp, 10);
                 if (endp == b) break;
-                sc->passBudget[n++] = v ? (uint32_t)v : 1u;
+                sc->passBudget[n++] = (uint32_t)(((v ? v : 1) + 1023) / 1024 * 1024); // multiples of the trace kernel's epoch (RT_WF_EPOCH)
                 b = (*endp == ',') ? endp + 1 : endp;
             }
             sc->passBudget[n++] = 0xffffffffu;

@@ -440,6 +440,12 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
 #ifndef RT_WF_LIST
 #define RT_WF_LIST 8              // occupied cells a lane may record before it has to test them (LDS: 4 B x 256 each)
 #endif
+#define RT_WF_SPIN_LIMIT 16384u
+#ifndef RT_WF_EPOCH
+#define RT_WF_EPOCH 1024          // cell visits between two in-workgroup compactions of the live rays.  A walk has at most
+                                  // 766 visits, so by default compaction never triggers: measured, re-packing (in the
+                                  // workgroup or by extra passes) costs more in flushes and barriers than it saves
+#endif
 #ifndef RT_WF_UNROLL
 #define RT_WF_UNROLL 4            // cell visits between two checks of the wave's walk/test decision
 #endif
@@ -451,10 +457,17 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
                                                                          const uint32_t pass, const uint32_t budgetPerRay)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
-    __shared__ uint32_t cellList[RT_WF_LIST][256]; // [entry][thread]: conflict-free, 4 B apart across a wave
-    __shared__ uint8_t ownerOf[4][RT_WF_LIST * 64];  // per wave: which lane recorded flattened cell item c
-    __shared__ unsigned long long keyOf[4][64];      // per wave and lane: min over its hit cells of (cell order << 32 | pair index)
-    __shared__ uint32_t spillWave[4], spillBase;
+    // One LDS block with two lives: while a wave walks and tests it holds the per-lane cell lists and the per-wave
+    // test scratch; at an epoch boundary (lists empty) it is the staging area of the workgroup's ray compaction.
+    constexpr int kStageWords = 16; // q cell endCell excluded | dx dy dz tmin | tmax o.xyz | d.xyz budget
+    constexpr int kListWords = RT_WF_LIST * 256, kOwnerWords = 4 * RT_WF_LIST * 64 / 4, kKeyWords = 4 * 64 * 2;
+    constexpr int kScratchWords = (kStageWords * 256 > kListWords + kOwnerWords + kKeyWords) ? kStageWords * 256 : kListWords + kOwnerWords + kKeyWords;
+    __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchWords];
+    uint32_t (*cellList)[256] = reinterpret_cast<uint32_t (*)[256]>(scratch);                                  // [entry][thread]
+    uint8_t (*ownerOf)[RT_WF_LIST * 64] = reinterpret_cast<uint8_t (*)[RT_WF_LIST * 64]>(scratch + kListWords); // per wave: lane that recorded item c
+    unsigned long long (*keyOf)[64] = reinterpret_cast<unsigned long long (*)[64]>(scratch + kListWords + kOwnerWords); // per wave and lane
+    uint32_t (*stage)[256] = reinterpret_cast<uint32_t (*)[256]>(scratch);                                     // [word][slot]
+    __shared__ uint32_t spillWave[4], spillBase, liveWave[4];
 
     // one workgroup per 256 entries of one shard's slice
     const uint32_t blocksPerShard = W.shardCap >> 8;
@@ -531,11 +544,12 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     }
 
     uint32_t budget = budgetPerRay;
+    uint32_t epochLeft = RT_WF_EPOCH; // cell visits left before the workgroup re-packs its rays
+    uint32_t spins = 0;               // walk-loop head iterations of this wave (guard against a logic error hanging the GPU)
 #ifdef RT_DIAG_STAMPS
     unsigned long long dgWalk = 0, dgTest = 0, dgWalkIters = 0, dgBatches = 0, dgTestLanes = 0, dgCells = 0;
     const unsigned long long dgStart = diag_stamp();
 #endif
-    uint32_t guard = 4096; // > 766 cell visits per walk (wave-uniform)
     uint32_t listed = 0;   // occupied cells recorded and not yet tested
     bool walkEnded = false; // the walk itself is over (end cell reached or the grid left): only recorded cells can still hit
 
@@ -550,17 +564,17 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
 #ifdef RT_DIAG_STAMPS
             dgWalkIters++;
 #endif
-            const bool canWalk = active && !walkEnded && budget != 0 && listed < RT_WF_LIST;
+            const bool canWalk = active && !walkEnded && budget != 0 && epochLeft != 0 && listed < RT_WF_LIST;
             const unsigned long long walkers = __ballot(canWalk);
             // A test batch costs a chain of dependent gathers whatever the number of lanes in it, a walking iteration is
             // cheap: walk until nobody can, or until the lanes stalled on a full list outnumber the walkers.
             if (walkers == 0ull) break;
-            const int stalled = __popcll(__ballot(active && !walkEnded && budget != 0 && listed >= RT_WF_LIST));
+            const int stalled = __popcll(__ballot(active && !walkEnded && budget != 0 && epochLeft != 0 && listed >= RT_WF_LIST));
             if (stalled * RT_WF_STALL_WEIGHT > __popcll(walkers)) break;
-            if (--guard == 0) break; // cannot happen (every iteration spends budget); keeps a logic error from hanging the GPU
+            if (++spins > RT_WF_SPIN_LIMIT) break; // cannot happen (a ray makes at most 766 visits); keeps a logic error from hanging the GPU
 #pragma unroll
             for (int u = 0; u < RT_WF_UNROLL; ++u) { // the checks above are re-done every RT_WF_UNROLL cell visits
-                if (active && !walkEnded && budget != 0 && listed < RT_WF_LIST) {
+                if (active && !walkEnded && budget != 0 && epochLeft != 0 && listed < RT_WF_LIST) {
                     // occupancy bit of this cell in its 4x4x4 block word
                     const uint32_t bit = (cell & 3u) | ((cell >> 6) & 12u) | ((cell >> 12) & 48u);
                     const uint32_t half = (bit & 32u) ? wordHi : wordLo;
@@ -571,6 +585,7 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
                         ++listed;
                     }
                     --budget;
+                    --epochLeft;
                     // the end cell ends the walk after it has been visited (:380-381)
                     bool done = (cell == endCell);
                     if (!done) {
@@ -681,17 +696,50 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
             W.res[q] = make_uint4(RT_NONE, __float_as_uint(tmax), 0u, 0u);
             active = false;
         }
-        // anything left to walk in this pass?
-        if (__ballot(active && budget != 0) == 0ull || guard == 0) break;
+        // anything left to walk in this epoch?
+        if (spins <= RT_WF_SPIN_LIMIT && __ballot(active && budget != 0 && epochLeft != 0) != 0ull) continue;
+
+        // ---- epoch boundary: the workgroup compacts its live rays into the lowest lanes, so that waves run full or not
+        // at all (the unbounded pass used to do 70 % of all wave-steps at 30 % lane utilisation).  All lists are empty
+        // here -- every recorded cell has been tested -- so only the DDA state travels.  Budgets are multiples of the
+        // epoch: the rays of a launch run out of budget together, at a boundary, and then all leave through the
+        // continuation queue below.
+        const bool live = active && budget != 0;
+        const unsigned long long liveMask = __ballot(live);
+        if (lane == 0) liveWave[wave] = (spins > RT_WF_SPIN_LIMIT) ? 0x40000000u : (uint32_t)__popcll(liveMask);
+        __syncthreads();
+        const uint32_t liveTotal = liveWave[0] + liveWave[1] + liveWave[2] + liveWave[3];
+        if (liveTotal == 0 || liveTotal >= 0x40000000u) break; // workgroup-uniform: nothing left, or a wave tripped its spin guard
+        uint32_t slot = (uint32_t)__popcll(liveMask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) slot += liveWave[w];
+        if (live) {
+            stage[0][slot] = q; stage[1][slot] = cell; stage[2][slot] = endCell; stage[3][slot] = excluded;
+            stage[4][slot] = __float_as_uint(dx); stage[5][slot] = __float_as_uint(dy); stage[6][slot] = __float_as_uint(dz);
+            stage[7][slot] = __float_as_uint(tmin); stage[8][slot] = __float_as_uint(tmax);
+            stage[9][slot] = __float_as_uint(o.x); stage[10][slot] = __float_as_uint(o.y); stage[11][slot] = __float_as_uint(o.z);
+            stage[12][slot] = __float_as_uint(d.x); stage[13][slot] = __float_as_uint(d.y); stage[14][slot] = __float_as_uint(d.z);
+            stage[15][slot] = budget;
+        }
+        __syncthreads();
+        active = threadIdx.x < liveTotal;
+        if (active) {
+            const uint32_t t = threadIdx.x;
+            q = stage[0][t]; cell = stage[1][t]; endCell = stage[2][t]; excluded = stage[3][t];
+            dx = __uint_as_float(stage[4][t]); dy = __uint_as_float(stage[5][t]); dz = __uint_as_float(stage[6][t]);
+            tmin = __uint_as_float(stage[7][t]); tmax = __uint_as_float(stage[8][t]);
+            o = mk(__uint_as_float(stage[9][t]), __uint_as_float(stage[10][t]), __uint_as_float(stage[11][t]));
+            d = mk(__uint_as_float(stage[12][t]), __uint_as_float(stage[13][t]), __uint_as_float(stage[14][t]));
+            budget = stage[15][t];
+            wordAt = ((cell >> 2) & 63u) | ((cell >> 4) & 0xFC0u) | ((cell >> 6) & 0x3F000u);
+            const GridBlock gb = gridBlock[wordAt];
+            wordLo = gb.lo; wordHi = gb.hi; wordRank = gb.rank;
+        }
+        walkEnded = false;
+        listed = 0;
+        epochLeft = RT_WF_EPOCH;
+        __syncthreads(); // the staging area becomes list storage again
     }
 
-#ifdef RT_DIAG_STAMPS
-    if (lane == 0) {
-        atomicAdd(&S.stats[0], diag_stamp() - dgStart); atomicAdd(&S.stats[1], dgWalk); atomicAdd(&S.stats[2], dgTest);
-        atomicAdd(&S.stats[3], dgWalkIters); atomicAdd(&S.stats[4], dgBatches); atomicAdd(&S.stats[5], dgTestLanes);
-        atomicAdd(&S.stats[6], 1ull); atomicAdd(&S.stats[7], dgCells);
-    }
-#endif
     // rays that are still walking leave through the continuation queue: one atomic per workgroup
     const unsigned long long spillMask = __ballot(active);
     if (lane == 0) spillWave[wave] = (uint32_t)__popcll(spillMask);
