@@ -199,6 +199,17 @@ def main():
         else:
             dom_name, dom_ms, dom_bytes = "rt_trace_kernel<false>", kernel_ms, b_local
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes of the dominant kernel per frame from the PMC passes committed under profiles/ (collected by
+        # scripts/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 x2 read correction);
+        # only reported when that profile is of this very workload and N=1
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic_lambert1m.json")))
+            key = dom_name.split(" ")[0] + ("<true>" if dom_name.startswith("wf_trace") else "")
+            if world == 1 and pipeline and prof.get("workload") == args.workload and args.samples == 1 and key in prof["per_frame"]:
+                traffic = int(prof["per_frame"][key]["hbm_bytes"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "Mrays/s (primary rays; each also traces its shadow/bounce rays) at ms/frame = ms_per_step",
             "value": round(primary_rays * args.steps / elapsed / 1e6, 3),
@@ -218,7 +229,7 @@ def main():
             "total_mrays_per_s": round(total_rays * args.steps / elapsed / 1e6, 3),
             "rays_per_frame": {"primary": int(primary_rays), "grid": int(total_stats["gridRays"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": dom_name, "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(dom_bytes),
                          "frame": {"device_ms": round(kernel_ms, 4), "frames": int(launches), "algorithmic_bytes": int(b_local),
                                    "achieved": round(b_local / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,

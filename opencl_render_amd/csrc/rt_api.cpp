@@ -355,7 +355,8 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         HIP_OK(hipGetDeviceProperties(&prop, sc->device));
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
         const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16 + 2 * 64;
-        const uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
+        uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
+        if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
         if (sb > d->sampleCount) sb = d->sampleCount;

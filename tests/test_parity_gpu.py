@@ -105,6 +105,40 @@ def test_fresh_scenes_match_oracle(seed):
     assert_planes(got, want, f"fresh seed {seed}")
 
 
+@pytest.mark.parametrize("name", ["mirror_hall", "mixed_materials_textured", "sparse_many_samples"])
+def test_megakernel_pipeline_matches_golden(name):
+    """The single-launch variant (pipeline 0) ships too: same planes."""
+    sc, want = load_golden_scene(name)
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.set_pipeline(R.PIPELINE_MEGAKERNEL)
+        rs.render()
+        assert_planes(rs.readback(), want, name + " (megakernel)")
+        rs.set_pipeline(R.PIPELINE_WAVEFRONT)
+        rs.render()
+        assert_planes(rs.readback([np.zeros(sc.pixels, np.uint16) for _ in range(3)]), want, name + " (wavefront)")
+    finally:
+        rs.close()
+
+
+def test_sample_batches_accumulate_in_order(monkeypatch):
+    """S=5 with a path-state budget that only fits 1 or 2 samples per batch: the per-sample truncated, saturating
+    accumulate (raytrace_opencl.c:726-741) must give the same planes however the samples are batched."""
+    sc, want = load_golden_scene("sparse_many_samples")  # 80x60, S=5
+    for mb in ("20", "40"):  # ~1 and ~2 samples per batch for one 128x128 tile
+        monkeypatch.setenv("RT_WF_STATE_MB", mb)
+        rs = R.ResidentScene(sc, 0)
+        try:
+            rs.stage_timing(True)
+            rs.render()
+            got = rs.readback()
+            _, rounds = rs.stage_times_ms()
+        finally:
+            rs.close()
+        assert_planes(got, want, f"state budget {mb} MB")
+    monkeypatch.delenv("RT_WF_STATE_MB")
+
+
 def test_determinism_two_renders_identical():
     sc, _ = load_golden_scene("mirror_hall")
     a = R.render_resident(sc, 0)
