@@ -200,10 +200,11 @@ int rtHipRenderTiles(rtHipScene *scene, void *stream);
 int rtHipSetPipeline(rtHipScene *scene, int pipeline);
 
 /* Per-stage device time: enable, render frames, then read the SUM over those frames in milliseconds for
- * [0] primary, [1] logic, [2] grid trace, [3] accumulate (HIP events on the launch stream; adds two event records per
- * launch, so leave it off in timed whole-frame runs).  *rounds = logic/trace rounds of the last frame. */
+ * [0] primary, [1] logic, [2] grid trace, [3] accumulate, [4] length sort of the trace input (HIP events on the launch
+ * stream; adds two event records per launch, so leave it off in timed whole-frame runs).  *rounds = logic/trace rounds
+ * of the last frame. */
 int rtHipStageTiming(rtHipScene *scene, int enable);
-int rtHipStageTimes(rtHipScene *scene, double ms[4], uint64_t *rounds);
+int rtHipStageTimes(rtHipScene *scene, double ms[5], uint64_t *rounds);
 
 /* Diagnostic: copies the scene's 8 device-side debug counters (and optionally clears them).  Synchronous. */
 int rtHipDebugCounters(rtHipScene *scene, unsigned long long out[8], int clear);

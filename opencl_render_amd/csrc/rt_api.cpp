@@ -34,6 +34,7 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
 extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
                                        uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
+extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
 
 namespace {
 
@@ -75,7 +76,7 @@ struct rtHipScene {
     uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
     uint32_t passCount = 1, passBudget[RT_WF_PASSES] = { 0xffffffffu }; // one unbounded pass measured best (1080p and 4K)
     uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
-    // per-stage device time of the frames since the last query: [primary, logic, trace, accum]
+    // per-stage device time of the frames since the last query: [primary, logic, trace, accum, sort]
     struct StageEvent { int stage; hipEvent_t a, b; };
     std::vector<StageEvent> stageEvents;
     size_t stageEventsUsed = 0;
@@ -354,7 +355,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, sc->device));
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 2 * 40 + 16 + 16 + 2 * 64;
+        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 8 + 16 + 2 * (2 * 40 + 16 + 2 * 64) + 16;
         uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
         if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
@@ -369,6 +370,8 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         RtWavefront &Wf = sc->wf;
         Wf.capacity = (uint32_t)cap;
         Wf.shardCap = (uint32_t)shardCap;
+        Wf.queueStride = (uint32_t)(2 * shardCap);
+        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path
         Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
         if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
             sc->alloc<float4>(cap, &Wf.cur0) || sc->alloc<float4>(cap, &Wf.cur1) || sc->alloc<float4>(cap, &Wf.cur2) ||
@@ -376,18 +379,25 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             sc->alloc<float4>(cap, &Wf.shF1) || sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(cap, &Wf.shToL) ||
             sc->alloc<float4>(cap, &Wf.shTex) || sc->alloc<float4>(cap, &Wf.shTransp) || sc->alloc<float4>(cap, &Wf.shRefl) ||
             sc->alloc<float4>(cap, &Wf.shLum) || sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) ||
-            sc->alloc<float4>(cap, &Wf.reqO[0]) || sc->alloc<float4>(cap, &Wf.reqO[1]) || sc->alloc<float4>(cap, &Wf.reqD[0]) ||
-            sc->alloc<float4>(cap, &Wf.reqD[1]) || sc->alloc<uint2>(cap, &Wf.reqX[0]) || sc->alloc<uint2>(cap, &Wf.reqX[1]) ||
-            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(pix * sb, &Wf.sampleOut) ||
-            sc->alloc<uint4>(cap * 4, &Wf.cont[0]) || sc->alloc<uint4>(cap * 4, &Wf.cont[1]) ||
-            sc->alloc<uint32_t>((uint64_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, &Wf.counts))
+            sc->alloc<unsigned long long>(cap, &Wf.rngL) || sc->alloc<uint4>(cap, &Wf.laRes) ||
+            sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
+            sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
+            sc->alloc<uint4>(qcap, &Wf.res) || sc->alloc<float4>(pix * sb, &Wf.sampleOut) ||
+            sc->alloc<uint4>(qcap * 4, &Wf.cont[0]) || sc->alloc<uint4>(qcap * 4, &Wf.cont[1]) ||
+            sc->alloc<uint32_t>((uint64_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, &Wf.counts) ||
+            sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(1, &Wf.sortTotal))
             return -1;
+        HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
+        Wf.sortMode = 1;  // length-sorted trace input (RT_WF_SORT=0: the trace kernel reads the request queues directly)
+        Wf.lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
+        if (const char *b = getenv("RT_WF_SORT")) Wf.sortMode = (b[0] != '0') ? 1u : 0u;
+        if (const char *b = getenv("RT_WF_LOOKAHEAD")) Wf.lookAhead = (b[0] != '0') ? 1u : 0u;
         Wf.contCounts = Wf.counts + 3 * RT_WF_SHARDS;
         HIP_OK(hipHostMalloc((void **)&sc->hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        sc->traceBlocks = (uint32_t)(cap / 256);  // one workgroup per 256 entries of every slice; surplus groups exit at once
+        sc->traceBlocks = (uint32_t)(qcap / 256);  // one workgroup per 256 entries of every queue slice; surplus groups exit at once
         (void)cus;
-        sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
+        sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((qcap + 255) / 256));
         if (sc->logicBlocks == 0) sc->logicBlocks = 1;
         if (const char *b = getenv("RT_WF_BUDGETS")) { // tuning aid: comma-separated cell-visit budgets; a final unbounded pass is appended
             uint32_t n = 0;
@@ -443,6 +453,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
             const uint32_t chunk = 4;
             for (uint32_t k = 0; k < chunk && r < RT_WF_MAX_ROUNDS; ++k, ++r) {
                 HIP_OK(stage(1, [&] { return rtw_launch_logic(&D, &Wf, r, sc->logicBlocks, st); }));
+                if (Wf.sortMode) HIP_OK(stage(4, [&] { return rtw_launch_sort(&D, &Wf, r + 1, sc->traceBlocks, st); }));
                 // cell-visit budgets per pass: a walk has at most 766 visits; the last pass is unbounded
                 for (uint32_t p = 0; p < sc->passCount; ++p)
                     HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, p, sc->passBudget[p], sc->traceBlocks, st); }));
@@ -555,11 +566,11 @@ int rtHipStageTiming(rtHipScene *sc, int enable)
     return 0;
 }
 
-int rtHipStageTimes(rtHipScene *sc, double ms[4], uint64_t *rounds)
+int rtHipStageTimes(rtHipScene *sc, double ms[5], uint64_t *rounds)
 {
     if (!sc || !ms) return fail("null argument");
     HIP_OK(hipSetDevice(sc->device));
-    for (int i = 0; i < 4; ++i) ms[i] = 0.0;
+    for (int i = 0; i < 5; ++i) ms[i] = 0.0;
     for (size_t i = 0; i < sc->stageEventsUsed; ++i) {
         HIP_OK(hipEventSynchronize(sc->stageEvents[i].b));
         float t = 0.f;

@@ -81,13 +81,19 @@ struct RtDevScene {
 #define RT_WF_MAX_ROUNDS 100000
 #define RT_WF_SHARDS 256      // every queue is cut into this many independent slices, each with its own counter
 #define RT_WF_PASSES 8        // at most this many trace passes per round; the last one runs every ray to its end
+#define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input: bin = (767 - predicted visits) / 12, 0 = longest
+#define RT_WF_SORT_COPIES 4   // independent histograms (workgroup % copies) to spread the atomics
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
     uint32_t samplesInBatch;
     // per-path state, indexed by path id
     unsigned long long *rng; // generator state (raytrace_opencl.c:474-481)
-    uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel  z: head | tail<<4 | stage<<8 | light<<16  w: hit triangle
+    unsigned long long *rngL; // second cursor into the same stream: where the CURRENT hit's light set-ups draw from (the
+                             // main cursor has already been moved past all draws of that hit when its spawns were computed)
+    uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel
+                             // z: head | tail<<4 | stage<<8 | lookahead state<<10 | lookahead ring index<<12 | light<<16   w: hit triangle
+    uint4 *laRes;            // answer of the path's look-ahead ray while it waits to be consumed
     float4 *outc;            // accumulated colour xyz, w: hit distance
     float4 *cur0, *cur1, *cur2; // ray in flight: o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera
     float4 *shN, *shWhere, *shF0, *shF1, *shAtt, *shToL; // n.xyz,l1 | where.xyz,l2 | face0.xyz,lmin | face1.xyz,lmax | atten | toLight
@@ -95,17 +101,27 @@ struct RtWavefront {
     float4 *ring;            // [capacity][12][3] queued rays, same packing as cur0..2
     // ray requests / results
     float4 *reqO[2], *reqD[2]; // o.xyz,tmin | d.xyz,tmax
-    uint2 *reqX[2];            // excluded triangle, path id
+    uint2 *reqX[2];            // excluded triangle, path id | (1u<<31 for the look-ahead request, which sits right after its path's main request)
     uint4 *res;                // hit triangle (0xffffffff = none), t, l1, l2 (float bits)
     // Queues are SHARDED: a path is born into shard (primary workgroup % RT_WF_SHARDS) and everything it ever emits --
     // ray requests, continuation entries -- goes to the same shard's slice [shard*shardCap, (shard+1)*shardCap) of the
     // queue arrays.  Appends therefore hit RT_WF_SHARDS different counters instead of one (a single address sustains
     // only ~90 atomics/us, which was the whole cost of the primary and logic kernels), and a slice can never overflow:
     // it holds at most the paths born into it.  Counters are small rings zeroed in-stream by the logic kernel.
-    uint32_t shardCap;         // entries per shard (multiple of 256); arrays hold RT_WF_SHARDS*shardCap entries
+    uint32_t shardCap;         // PATHS per shard (multiple of 256): path-state arrays hold RT_WF_SHARDS*shardCap entries
+    uint32_t queueStride;      // queue ENTRIES per shard = 2*shardCap: a path may have two rays in flight (its hit's shadow
+                               // ray and a look-ahead trace of the next ring entry); req*/res/cont arrays use this stride
     uint32_t *counts;          // [3][RT_WF_SHARDS] fresh-request queue length; round r reads [r%3], appends to [(r+1)%3]
     uint32_t *contCounts;      // [RT_WF_PASSES][RT_WF_SHARDS] continuation entries appended by each trace pass
     uint4 *cont[2];            // [capacity][4], self-contained: {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz,-}
+    // Length-sorted trace input (wf_setup_kernel / wf_scatter_kernel): a round's requests are turned into self-contained
+    // entries (DDA start state computed once), keyed by the PREDICTED number of cell visits (exact for rays that hit
+    // nothing) and counting-sorted longest first, so that a wave holds rays of similar length and the longest walks of
+    // the round start first.  cont[0] is the staging area, cont[1] the sorted array (no continuation passes in this mode).
+    uint32_t sortMode;         // 0: trace reads the sharded request queues directly; 1: setup -> scatter -> trace(sorted)
+    uint32_t lookAhead;        // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
+    uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
+    uint32_t *sortTotal;       // [1] entries in the sorted array
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
     const bool born = valid && hit_tri != RT_NONE;
     // workgroups are dealt to the shards round-robin: concurrently running groups append to different counters
     const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) % RT_WF_SHARDS;
-    const uint32_t a = shard * W.shardCap + wave_append(&W.counts[shard], born); // round 0 uses ring slot 0
+    const uint32_t slot0 = wave_append(&W.counts[shard], born); // round 0 uses ring slot 0
+    const uint32_t a = shard * W.shardCap + slot0;    // path id
+    const uint32_t q0 = shard * W.queueStride + slot0; // its round-0 queue entry: the primary hit plays the answered request
     if (born) {
         W.rng[a] = rng;
         W.meta[a] = make_uint4(outSlot, localPixel, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), hit_tri);
@@ -142,12 +144,20 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
         W.cur0[a] = pack4(ld3(S.eye), 0.f);
         W.cur1[a] = pack4(dir, __uint_as_float(RT_NONE));
         W.cur2[a] = make_float4(1.f, 1.f, 1.f, __uint_as_float((12u << 1) | 1u)); // maxBounces 12, fromCamera (:492,:505)
-        W.reqX[0][a] = make_uint2(RT_NONE, a);
-        W.res[a] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
+        W.reqX[0][q0] = make_uint2(RT_NONE, a);
+        W.res[q0] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
     }
 }
 
 // ---- stage 2: per-path state machine ---------------------------------------------------------------------------------
+// Two rays of a path may be in flight at once: the current hit's shadow ray (or the ring ray being traced) and a
+// LOOK-AHEAD trace of the next ring entry.  That is legal because nothing about a spawned ray depends on the shadow
+// rays of the hit that spawned it -- only the ORDER in which colour is accumulated does, and that order is kept: the
+// machine below is still strictly sequential per path, it merely finds some answers already there.  To know the spawned
+// rays before the light loop has run, a hit's spawns are computed when it is shaded: the main generator cursor is moved
+// past the light loop's draws (their count depends on the generator alone) to make the diffuse draw (:671), and a second
+// cursor (rngL) replays the light draws when each light is actually set up.  The draw order of raytrace_opencl.c is
+// unchanged, so are the results.
 #ifndef RT_WF_LOGIC_WAVES
 #define RT_WF_LOGIC_WAVES 2
 #endif
@@ -168,23 +178,28 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
         if (gid < RT_WF_SHARDS) W.counts[((round + 2) % 3) * RT_WF_SHARDS + gid] = 0u;
         if (gid < RT_WF_PASSES * RT_WF_SHARDS) W.contCounts[gid] = 0u;
+        if (gid < RT_WF_SORT_COPIES * RT_WF_SORT_BINS) W.sortHist[gid] = 0u; // filled by this round's wf_setup_kernel
     }
 
-    const uint32_t chunksPerShard = W.shardCap >> 6;
+    const uint32_t chunksPerShard = W.queueStride >> 6;
     for (uint32_t chunk = waveId; chunk < RT_WF_SHARDS * chunksPerShard; chunk += waves) {
         const uint32_t shard = chunk / chunksPerShard;
         const uint32_t total = countIn[shard];
         const uint32_t local = (chunk - shard * chunksPerShard) * 64 + lane;
         if ((chunk - shard * chunksPerShard) * 64 >= total) continue; // wave-uniform
-        const uint32_t q = shard * W.shardCap + local;
-        const bool live = local < total;
-        bool emit = false;
-        V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
-        float rtmin = 0.f, rtmax = 0.f;
-        uint32_t rexcl = RT_NONE, a = 0;
+        const uint32_t q = shard * W.queueStride + local;
+        bool live = local < total;
+        bool emit = false, emitLa = false;
+        V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), lo3 = mk(0, 0, 0), ld3v = mk(0, 0, 0);
+        float rtmin = 0.f, rtmax = 0.f, latmin = 0.f;
+        uint32_t rexcl = RT_NONE, laexcl = RT_NONE, a = 0;
 
         if (live) {
-            a = W.reqX[in][q].y;
+            const uint2 rx = W.reqX[in][q];
+            if (rx.y & 0x80000000u) live = false; // a look-ahead request: its path is driven from the entry before it
+            a = rx.y & 0x7fffffffu;
+        }
+        if (live) {
             const uint4 r = W.res[q];
             uint32_t res_tri = r.x;
             float res_t = __uint_as_float(r.y), res_l1 = __uint_as_float(r.z), res_l2 = __uint_as_float(r.w);
@@ -196,8 +211,13 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             float hit_t = oc.w;
             uint32_t hit_tri = meta.w;
             int head = (int)(meta.z & 15u), tail = (int)((meta.z >> 4) & 15u);
-            const uint32_t stage = (meta.z >> 8) & 255u;
+            const uint32_t stage = (meta.z >> 8) & 3u;
+            uint32_t laState = (meta.z >> 10) & 3u; // 0 none, 1 requested last round (answer at q+1), 2 answer kept in laRes
+            int laIndex = (int)((meta.z >> 12) & 15u);
             uint32_t j = meta.z >> 16;
+            uint4 laAns = make_uint4(RT_NONE, 0u, 0u, 0u);
+            if (laState == 1u) { laAns = W.res[q + 1]; laState = 2u; }
+            else if (laState == 2u) laAns = W.laRes[a];
             float4 c0 = W.cur0[a], c1 = W.cur1[a], c2 = W.cur2[a];
             V3 cur_o = xyz(c0), cur_d = xyz(c1), cur_w = xyz(c2);
             float cur_tmin = c0.w;
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             V3 n = mk(0, 0, 0), where = mk(0, 0, 0), face0 = mk(0, 0, 0), face1 = mk(0, 0, 0), atten = mk(0, 0, 0), toL = mk(0, 0, 0);
             V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
             float hit_l1 = 0.f, hit_l2 = 0.f, lmin = 0.f, lmax = 0.f;
+            uint64_t rngL = 0;
 
             enum { PC_RAY_RESULT, PC_SHADOW_RESULT, PC_LIGHT_SETUP, PC_LIGHT_ACCUM, PC_SHADE_END, PC_NEXT_RAY, PC_EXIT };
             int pc = PC_RAY_RESULT;
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 face0 = xyz(f0); lmin = f0.w; face1 = xyz(f1); lmax = f1.w;
                 atten = xyz(W.shAtt[a]); toL = xyz(W.shToL[a]);
                 tex = xyz(W.shTex[a]); transp = xyz(W.shTransp[a]); refl = xyz(W.shRefl[a]); lum = xyz(W.shLum[a]);
+                rngL = W.rngL[a];
                 pc = PC_SHADOW_RESULT;
             }
             bool finished = false, freshShading = false, curDirty = false;
@@ -247,6 +269,52 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         w = S.matSize[2 * (mc + CH_LUMINANCE)];
                         if (0 < w) lum = texel<false>(S, sh, S.matStart[mc + CH_LUMINANCE], w, S.matSize[2 * (mc + CH_LUMINANCE) + 1], uv, hit_l1, hit_l2, raw, cn);
                     }
+                    // The light loop (:563-637) will draw from here ...
+                    rngL = rng;
+                    // ... and the main cursor skips those draws: one GetSpherePoint per light of a sampled type (:573,:595)
+                    for (uint32_t k = 0; k < S.lightCount; ++k) {
+                        const int type = S.lightType[k];
+                        if ((type >= 1 && type <= 9)) (void)sphere_point(rng, 1.f);
+                    }
+                    // the hit's spawns (:656-722), ahead of its light loop: nothing below depends on the face lights
+                    if (cur_bounces > 0) {
+                        const int front = (dot3(n, cur_d) <= 0.f) ? 1 : 0;
+                        const float total_rt = RT_MAX2(RT_MAX2(refl.x + transp.x, refl.y + transp.y), refl.z + transp.z);
+                        const float dif = (total_rt < 1.f) ? 1.f - total_rt : 0.f;
+                        float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
+                        bool open = true;
+                        V3 w = mk(cur_w.x * tex.x * dif, cur_w.y * tex.y * dif, cur_w.z * tex.z * dif);
+                        if (3.f / 256.f <= w.x + w.y + w.z) { // diffuse bounce (:664-683)
+                            V3 nd = sphere_point(rng, 1.f);
+                            if (front != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
+                            ringA[tail * 3 + 0] = pack4(where, 0.f);
+                            ringA[tail * 3 + 1] = pack4(nd, __uint_as_float(hit_tri));
+                            ringA[tail * 3 + 2] = pack4(w, __uint_as_float(0u));
+                            tail = (tail + 1) % RT_RING;
+                            if ((tail + 1) % RT_RING == head) open = false;
+                        }
+                        if (open) { // mirror (:686-705)
+                            w = mk(cur_w.x * tex.x * refl.x, cur_w.y * tex.y * refl.y, cur_w.z * tex.z * refl.z);
+                            if (3.f / 256.f <= w.x + w.y + w.z) {
+                                const float two = -2.f * dot3(n, cur_d);
+                                const V3 md = mk(cur_d.x + two * n.x, cur_d.y + two * n.y, cur_d.z + two * n.z);
+                                ringA[tail * 3 + 0] = pack4(where, 0.f);
+                                ringA[tail * 3 + 1] = pack4(md, __uint_as_float(hit_tri));
+                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float((uint32_t)(cur_bounces - 1) << 1));
+                                tail = (tail + 1) % RT_RING;
+                                if ((tail + 1) % RT_RING == head) open = false;
+                            }
+                        }
+                        if (open) { // see-through continuation (:707-722)
+                            w = mk(cur_w.x * tex.x * transp.x, cur_w.y * tex.y * transp.y, cur_w.z * tex.z * transp.z);
+                            if (3.f / 256.f <= w.x + w.y + w.z) {
+                                ringA[tail * 3 + 0] = pack4(cur_o, hit_t);
+                                ringA[tail * 3 + 1] = pack4(cur_d, __uint_as_float(hit_tri));
+                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float(((uint32_t)(cur_bounces - 1) << 1) | (uint32_t)cur_fromCamera));
+                                tail = (tail + 1) % RT_RING;
+                            }
+                        }
+                    }
                     j = 0;
                     freshShading = true;
                     pc = PC_LIGHT_SETUP;
@@ -256,7 +324,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     lmin = 0.f; lmax = 0.f;
                     const int type = S.lightType[j];
                     if (type == 1 || type == 2 || type == 7 || type == 8 || type == 9) {
-                        const V3 r = sphere_point(rng, S.lightRadius[j]);
+                        const V3 r = sphere_point(rngL, S.lightRadius[j]);
                         const float *lp = S.lightPos + 4 * j;
                         toL.x = r.x + lp[0] - where.x;
                         toL.y = r.y + lp[1] - where.y;
@@ -266,7 +334,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         toL.x *= inv; toL.y *= inv; toL.z *= inv;
                     } else if (type >= 3 && type <= 6) {
                         const float *ld = S.lightDir + 4 * j;
-                        toL = sphere_point(rng, S.lightSpread[j]);
+                        toL = sphere_point(rngL, S.lightSpread[j]);
                         toL.x -= ld[0]; toL.y -= ld[1]; toL.z -= ld[2];
                         const float inv = 1.f / sqrt_rn(dot3(toL, toL));
                         toL.x *= inv; toL.y *= inv; toL.z *= inv;
@@ -312,7 +380,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     }
                     ++j;
                     pc = PC_LIGHT_SETUP;
-                } else if (pc == PC_SHADE_END) { // :639-723
+                } else if (pc == PC_SHADE_END) { // :639-653 (the spawns of :656-722 were made when the hit was shaded)
                     out.x += (1.f - out.x) * lum.x * cur_w.x;
                     out.y += (1.f - out.y) * lum.y * cur_w.y;
                     out.z += (1.f - out.z) * lum.z * cur_w.z;
@@ -321,43 +389,6 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     out.x += (1.f - out.x) * cur_w.x * (1.f - transp.x) * tex.x * lit.x;
                     out.y += (1.f - out.y) * cur_w.y * (1.f - transp.y) * tex.y * lit.y;
                     out.z += (1.f - out.z) * cur_w.z * (1.f - transp.z) * tex.z * lit.z;
-                    if (cur_bounces > 0) {
-                        const float total_rt = RT_MAX2(RT_MAX2(refl.x + transp.x, refl.y + transp.y), refl.z + transp.z);
-                        const float dif = (total_rt < 1.f) ? 1.f - total_rt : 0.f;
-                        float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
-                        bool open = true;
-                        V3 w = mk(cur_w.x * tex.x * dif, cur_w.y * tex.y * dif, cur_w.z * tex.z * dif);
-                        if (3.f / 256.f <= w.x + w.y + w.z) { // diffuse bounce (:664-683)
-                            V3 nd = sphere_point(rng, 1.f);
-                            if (front != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
-                            ringA[tail * 3 + 0] = pack4(where, 0.f);
-                            ringA[tail * 3 + 1] = pack4(nd, __uint_as_float(hit_tri));
-                            ringA[tail * 3 + 2] = pack4(w, __uint_as_float(0u));
-                            tail = (tail + 1) % RT_RING;
-                            if ((tail + 1) % RT_RING == head) open = false;
-                        }
-                        if (open) { // mirror (:686-705)
-                            w = mk(cur_w.x * tex.x * refl.x, cur_w.y * tex.y * refl.y, cur_w.z * tex.z * refl.z);
-                            if (3.f / 256.f <= w.x + w.y + w.z) {
-                                const float two = -2.f * dot3(n, cur_d);
-                                const V3 md = mk(cur_d.x + two * n.x, cur_d.y + two * n.y, cur_d.z + two * n.z);
-                                ringA[tail * 3 + 0] = pack4(where, 0.f);
-                                ringA[tail * 3 + 1] = pack4(md, __uint_as_float(hit_tri));
-                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float((uint32_t)(cur_bounces - 1) << 1));
-                                tail = (tail + 1) % RT_RING;
-                                if ((tail + 1) % RT_RING == head) open = false;
-                            }
-                        }
-                        if (open) { // see-through continuation (:707-722)
-                            w = mk(cur_w.x * tex.x * transp.x, cur_w.y * tex.y * transp.y, cur_w.z * tex.z * transp.z);
-                            if (3.f / 256.f <= w.x + w.y + w.z) {
-                                ringA[tail * 3 + 0] = pack4(cur_o, hit_t);
-                                ringA[tail * 3 + 1] = pack4(cur_d, __uint_as_float(hit_tri));
-                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float(((uint32_t)(cur_bounces - 1) << 1) | (uint32_t)cur_fromCamera));
-                                tail = (tail + 1) % RT_RING;
-                            }
-                        }
-                    }
                     pc = PC_NEXT_RAY;
                 } else { // PC_NEXT_RAY (:509)
                     head = (head + 1) % RT_RING;
@@ -373,9 +404,26 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     if (cur_fromCamera) {
                         res_tri = camera_scan(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         pc = PC_RAY_RESULT;
+                    } else if (laState == 2u && laIndex == head) { // traced ahead of time: the answer is already here
+                        res_tri = laAns.x; res_t = __uint_as_float(laAns.y); res_l1 = __uint_as_float(laAns.z); res_l2 = __uint_as_float(laAns.w);
+                        laState = 0u;
+                        pc = PC_RAY_RESULT;
                     } else {
                         emit = true; emitStage = WS_RAY; ro = cur_o; rd = cur_d; rtmin = cur_tmin; rtmax = RT_INF; rexcl = cur_excl;
                         pc = PC_EXIT;
+                    }
+                }
+            }
+
+            // Leaving with a request and no look-ahead outstanding: start the next ring entry's grid walk as well.
+            if (!finished && laState == 0u && W.lookAhead) {
+                const int nx = (head + 1) % RT_RING;
+                if (nx != tail) {
+                    const float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
+                    const float4 n0 = ringA[nx * 3 + 0], n1 = ringA[nx * 3 + 1], n2 = ringA[nx * 3 + 2];
+                    if ((__float_as_uint(n2.w) & 1u) == 0u) { // a grid ray (camera-type rays are answered inline)
+                        emitLa = true; lo3 = xyz(n0); latmin = n0.w; ld3v = xyz(n1); laexcl = __float_as_uint(n1.w);
+                        laState = 1u; laIndex = nx;
                     }
                 }
             }
@@ -386,13 +434,16 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 // park the path in HBM until the grid has answered
                 W.rng[a] = rng;
                 W.outc[a] = pack4(out, hit_t);
-                W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | (j << 16), hit_tri);
+                W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | (laState << 10) |
+                                                       ((uint32_t)laIndex << 12) | (j << 16), hit_tri);
+                if (laState == 2u) W.laRes[a] = laAns;
                 if (curDirty) { // the ray in flight changed (popped from the ring) since the path was loaded
                     W.cur0[a] = pack4(cur_o, cur_tmin);
                     W.cur1[a] = pack4(cur_d, __uint_as_float(cur_excl));
                     W.cur2[a] = pack4(cur_w, __uint_as_float(((uint32_t)cur_bounces << 1) | (uint32_t)cur_fromCamera));
                 }
                 if (emitStage == WS_SHADOW) {
+                    W.rngL[a] = rngL;
                     W.shF0[a] = pack4(face0, lmin);
                     W.shF1[a] = pack4(face1, lmax);
                     W.shAtt[a] = pack4(atten, 0.f);
@@ -408,13 +459,159 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 }
             }
         }
-        // every lane of the wave arrives here: one atomic per wave for the rays of the next round
-        const uint32_t slot = shard * W.shardCap + wave_append(&countOut[shard], emit);
+        // every lane of the wave arrives here: one atomic per wave for the requests of the next round; a path's
+        // look-ahead request sits right behind its main request
+        const uint32_t mineN = (emit ? 1u : 0u) + (emitLa ? 1u : 0u);
+        uint32_t incl = mineN;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += up;
+        }
+        const uint32_t waveTotal = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (waveTotal) {
+            if (lane == 63) base = atomicAdd(&countOut[shard], waveTotal);
+            base = __shfl(base, 63, 64);
+        }
+        const uint32_t slot = shard * W.queueStride + base + incl - mineN;
         if (emit) {
             W.reqO[outq][slot] = pack4(ro, rtmin);
             W.reqD[outq][slot] = pack4(rd, rtmax);
             W.reqX[outq][slot] = make_uint2(rexcl, a);
         }
+        if (emitLa) {
+            W.reqO[outq][slot + 1] = pack4(lo3, latmin);
+            W.reqD[outq][slot + 1] = pack4(ld3v, RT_INF);
+            W.reqX[outq][slot + 1] = make_uint2(laexcl, a | 0x80000000u);
+        }
+    }
+}
+
+// ---- stage 2b: length-sorted trace input ---------------------------------------------------------------------------
+// A round lasts as long as its longest wave, and a wave as long as its longest ray (walks have 1..766 cell visits, 167 on
+// average).  Where a ray LEAVES the grid is cheap to compute (three divides and three plane searches), and for a ray that
+// hits nothing that gives its exact number of cell visits.  wf_setup_kernel turns every request into a self-contained
+// entry (the DDA start state of raytrace_opencl.c:351-362,383-385, computed once here instead of in the trace kernel),
+// keys it by predicted visits and counts it into RT_WF_SORT_BINS classes; wf_scatter_kernel moves the entries to their
+// sorted positions, longest class first.  Waves then hold rays of similar length (lane utilisation of the walk) and the
+// workgroups with the longest walks are dispatched first (the round no longer ends with a few stragglers).  Only the
+// ORDER in which rays are traced changes; every ray's arithmetic is untouched.
+__global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+{
+    __shared__ float planes[3 * (RT_GRID_DIV + 1)];
+    __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
+    const uint32_t blocksPerShard = W.queueStride >> 8;
+    const uint32_t shard = blockIdx.x / blocksPerShard;
+    const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
+    const uint32_t total = W.counts[(round % 3) * RT_WF_SHARDS + shard];
+    if (local0 >= total) return; // whole workgroup beyond the slice's entries
+    for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
+    if (threadIdx.x < RT_WF_SORT_BINS) binCount[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const uint32_t in = round & 1;
+    const uint32_t mine = shard * W.queueStride + local0 + threadIdx.x;
+    const bool active = local0 + threadIdx.x < total;
+    const uint32_t copy = blockIdx.x % RT_WF_SORT_COPIES;
+    const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
+    const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
+    V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+    float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    uint32_t excluded = RT_NONE, cell = 0, endCell = 0xffffffffu, bin = 0, rank = 0;
+    if (active) {
+        const float4 ro = W.reqO[in][mine], rd = W.reqD[in][mine];
+        o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
+        excluded = W.reqX[in][mine].x;
+        // start / end cells (:351-362)
+        int cx = 0, cy = 0, cz = 0, ex = 0, ey = 0, ez = 0;
+        V3 from = along(o, tmin, d);
+        bind_in_cube(from, d, lo, hi);
+#pragma unroll
+        for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+            if (planes[cx + div] < from.x) cx += div;
+            if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
+            if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
+        }
+        cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
+        V3 to;
+        if (tmax < RT_INF) {
+            to = along(o, tmax, d);
+            bind_in_cube(to, d, lo, hi);
+        } else {
+            // scheduling key only: the point where the ray leaves the grid (never used for the result)
+            float te = RT_INF;
+            if (d.x != 0.f) { const float t = (((0.f < d.x) ? hi.x : lo.x) - o.x) / d.x; if (t < te) te = t; }
+            if (d.y != 0.f) { const float t = (((0.f < d.y) ? hi.y : lo.y) - o.y) / d.y; if (t < te) te = t; }
+            if (d.z != 0.f) { const float t = (((0.f < d.z) ? hi.z : lo.z) - o.z) / d.z; if (t < te) te = t; }
+            to = (te < RT_INF) ? along(o, te, d) : from;
+        }
+#pragma unroll
+        for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+            if (planes[ex + div] < to.x) ex += div;
+            if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
+            if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
+        }
+        if (tmax < RT_INF) endCell = (uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16);
+        // distances from the ray ORIGIN to the next plane of each axis (:383-385)
+        dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
+        dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
+        dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
+        // every step moves one axis by one cell in a fixed direction: visits = Manhattan distance + 1
+        uint32_t visits = (uint32_t)(abs(ex - cx) + abs(ey - cy) + abs(ez - cz)) + 1u;
+        if (visits > 767u) visits = 767u;
+        bin = (767u - visits) / 12u;
+        rank = atomicAdd(&binCount[bin], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < RT_WF_SORT_BINS) {
+        const uint32_t n = binCount[threadIdx.x];
+        binBase[threadIdx.x] = n ? atomicAdd(&W.sortHist[copy * RT_WF_SORT_BINS + threadIdx.x], n) : 0u;
+    }
+    __syncthreads();
+    if (active) {
+        uint4 *stagingOut = W.cont[0] + 4 * (size_t)mine;
+        stagingOut[0] = make_uint4(mine, cell | ((bin | (copy << 6)) << 24), endCell, excluded);
+        stagingOut[1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(tmin));
+        stagingOut[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+        stagingOut[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), binBase[bin] + rank);
+    }
+}
+
+__global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round)
+{
+    __shared__ uint32_t base[RT_WF_SORT_BINS * RT_WF_SORT_COPIES];
+    const uint32_t blocksPerShard = W.queueStride >> 8;
+    const uint32_t shard = blockIdx.x / blocksPerShard;
+    const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
+    const uint32_t total = W.counts[(round % 3) * RT_WF_SHARDS + shard];
+    if (local0 >= total && blockIdx.x != 0) return; // workgroup 0 always publishes the total
+    if (threadIdx.x < RT_WF_SORT_BINS) { // one wave: exclusive prefix over (bin, copy), bin-major
+        uint32_t h[RT_WF_SORT_COPIES], sum = 0;
+#pragma unroll
+        for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { h[c] = W.sortHist[c * RT_WF_SORT_BINS + threadIdx.x]; sum += h[c]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += up;
+        }
+        uint32_t at = incl - sum;
+#pragma unroll
+        for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { base[threadIdx.x * RT_WF_SORT_COPIES + c] = at; at += h[c]; }
+        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) W.sortTotal[0] = incl;
+    }
+    __syncthreads();
+    if (local0 + threadIdx.x < total) {
+        const uint32_t mine = shard * W.queueStride + local0 + threadIdx.x;
+        const uint4 *stagingIn = W.cont[0] + 4 * (size_t)mine;
+        uint4 e0 = stagingIn[0], e1 = stagingIn[1], e2 = stagingIn[2], e3 = stagingIn[3];
+        const uint32_t tag = e0.y >> 24; // bin | copy << 6
+        const uint32_t at = base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + e3.w;
+        e0.y &= 0xffffffu;
+        e3.w = 0u;
+        uint4 *sortedOut = W.cont[1] + 4 * (size_t)at;
+        sortedOut[0] = e0; sortedOut[1] = e1; sortedOut[2] = e2; sortedOut[3] = e3;
     }
 }
 
@@ -452,7 +649,8 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
 #ifndef RT_WF_STALL_WEIGHT
 #define RT_WF_STALL_WEIGHT 1      // test once (lanes stalled on a full list) x weight exceeds the lanes still walking
 #endif
-template <bool FRESH>
+enum { TRACE_FRESH = 0, TRACE_CONT = 1, TRACE_SORTED = 2 }; // where a launch takes its rays from
+template <int MODE>
 __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
                                                                          const uint32_t pass, const uint32_t budgetPerRay)
 {
@@ -469,15 +667,17 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     uint32_t (*stage)[256] = reinterpret_cast<uint32_t (*)[256]>(scratch);                                     // [word][slot]
     __shared__ uint32_t spillWave[4], spillBase, liveWave[4];
 
-    // one workgroup per 256 entries of one shard's slice
-    const uint32_t blocksPerShard = W.shardCap >> 8;
-    const uint32_t shard = blockIdx.x / blocksPerShard;
-    const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
-    // input: the round's fresh requests (pass 0) or what the previous pass spilled
-    const uint32_t total = FRESH ? W.counts[(round % 3) * RT_WF_SHARDS + shard] : W.contCounts[(pass - 1) * RT_WF_SHARDS + shard];
-    if (local0 >= total) return; // whole workgroup beyond the slice's entries
+    constexpr bool FRESH = (MODE == TRACE_FRESH);
+    // one workgroup per 256 entries of one shard's slice, or (sorted input) of the whole sorted array
+    const uint32_t blocksPerShard = W.queueStride >> 8;
+    const uint32_t shard = (MODE == TRACE_SORTED) ? blockIdx.x % RT_WF_SHARDS : blockIdx.x / blocksPerShard;
+    const uint32_t local0 = (MODE == TRACE_SORTED) ? blockIdx.x * 256 : (blockIdx.x - shard * blocksPerShard) * 256;
+    // input: the round's fresh requests (pass 0), what the previous pass spilled, or the round's length-sorted entries
+    const uint32_t total = (MODE == TRACE_SORTED) ? W.sortTotal[0]
+                         : FRESH ? W.counts[(round % 3) * RT_WF_SHARDS + shard] : W.contCounts[(pass - 1) * RT_WF_SHARDS + shard];
+    if (local0 >= total) return; // whole workgroup beyond the entries
     const uint32_t localIdx = local0 + threadIdx.x;
-    const uint32_t mine = shard * W.shardCap + localIdx;
+    const uint32_t mine = (MODE == TRACE_SORTED) ? localIdx : shard * W.queueStride + localIdx;
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
@@ -746,7 +946,7 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t n = spillWave[0] + spillWave[1] + spillWave[2] + spillWave[3];
-        spillBase = shard * W.shardCap + (n ? atomicAdd(&W.contCounts[pass * RT_WF_SHARDS + shard], n) : 0u);
+        spillBase = shard * W.queueStride + (n ? atomicAdd(&W.contCounts[pass * RT_WF_SHARDS + shard], n) : 0u);
     }
     __syncthreads();
     if (active) {
@@ -803,8 +1003,17 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
 extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
                                        uint32_t blocks, hipStream_t stream)
 {
-    if (pass == 0) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
-    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
+    if (pass == 0 && wf->sortMode) hipLaunchKernelGGL(wf_trace_kernel<TRACE_SORTED>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
+    else if (pass == 0) hipLaunchKernelGGL(wf_trace_kernel<TRACE_FRESH>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
+    else hipLaunchKernelGGL(wf_trace_kernel<TRACE_CONT>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
+    return hipGetLastError();
+}
+
+// setup + scatter of one round's requests (sorted trace input); same grid as the trace kernel
+extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wf_setup_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round);
     return hipGetLastError();
 }
 

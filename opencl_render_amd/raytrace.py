@@ -124,7 +124,7 @@ def lib() -> C.CDLL:
     L.rtHipDebugCounters.argtypes = [vp, C.POINTER(C.c_uint64 * 8), C.c_int]
     L.rtHipSetPipeline.argtypes = [vp, C.c_int]
     L.rtHipStageTiming.argtypes = [vp, C.c_int]
-    L.rtHipStageTimes.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
+    L.rtHipStageTimes.argtypes = [vp, C.POINTER(C.c_double * 5), C.POINTER(u64)]
     L.rtHipTileBuffer.restype = vp
     L.rtHipTileBuffer.argtypes = [vp]
     L.rtHipTileBufferBytes.restype = u64
@@ -312,9 +312,9 @@ class ResidentScene:
 
     def stage_times_ms(self):
         """Sum over the frames since stage_timing(True): dict of stage -> ms, and rounds of the last frame."""
-        ms, rounds = (C.c_double * 4)(), C.c_uint64()
+        ms, rounds = (C.c_double * 5)(), C.c_uint64()
         self._check(lib().rtHipStageTimes(self.handle, C.byref(ms), C.byref(rounds)), "rtHipStageTimes")
-        return dict(primary=ms[0], logic=ms[1], trace=ms[2], accum=ms[3]), rounds.value
+        return dict(primary=ms[0], logic=ms[1], trace=ms[2], accum=ms[3], sort=ms[4]), rounds.value
 
     def debug_counters(self, clear: bool = True):
         out = (C.c_uint64 * 8)()
