@@ -273,6 +273,15 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             std::vector<uint2> range(cellFirst.size() - 1);
             for (size_t k = 0; k + 1 < cellFirst.size(); ++k) range[k] = make_uint2(cellFirst[k], cellFirst[k + 1]);
             if (sc->upload(block.data(), block.size(), &D.gridBlock, "gridBlock")) return -1;
+            {
+                std::vector<uint32_t> sparse((size_t)3 * ((63u << 16 | 63u << 8 | 63u) + 1u), 0u);
+                for (size_t b = 0; b < blocks; ++b) {
+                    const size_t at = (b % 64) | (((b / 64) % 64) << 8) | ((b / 4096) << 16);
+                    sparse[3 * at + 0] = block[3 * b + 0]; sparse[3 * at + 1] = block[3 * b + 1]; sparse[3 * at + 2] = block[3 * b + 2];
+                }
+                if (sc->upload(sparse.data(), sparse.size(), &D.gridBlockSparse, "gridBlockSparse")) return -1;
+                HIP_OK(hipStreamSynchronize(sc->stream)); // `sparse` is freed at the end of this scope
+            }
             if (sc->upload(range.data(), range.size(), &D.cellRange, "cellRange")) return -1;
             uint32_t *dPairTri = nullptr;
             HIP_OK(hipMalloc((void **)&dPairTri, (size_t)(listSize ? listSize : 1) * 4));
@@ -388,9 +397,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(1, &Wf.sortTotal))
             return -1;
         HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
-        Wf.sortMode = 1;  // length-sorted trace input (RT_WF_SORT=0: the trace kernel reads the request queues directly)
+        Wf.sortMode = 2;  // length-sorted trace input + lean trace kernel (RT_WF_SORT=0: request queues directly, 1: sorted + general kernel)
         Wf.lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
-        if (const char *b = getenv("RT_WF_SORT")) Wf.sortMode = (b[0] != '0') ? 1u : 0u;
+        if (const char *b = getenv("RT_WF_SORT")) Wf.sortMode = (b[0] >= '0' && b[0] <= '2') ? (uint32_t)(b[0] - '0') : 2u;
         if (const char *b = getenv("RT_WF_LOOKAHEAD")) Wf.lookAhead = (b[0] != '0') ? 1u : 0u;
         Wf.contCounts = Wf.counts + 3 * RT_WF_SHARDS;
         HIP_OK(hipHostMalloc((void **)&sc->hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));

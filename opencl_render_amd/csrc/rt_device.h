@@ -53,6 +53,10 @@ struct RtDevScene {
     //                     contiguous: {a.xyz, triangleId} {n.xyz, -} {ab.xyz, abab} {ac.xyz, acac}
     //                     (plane test = first two float4; abac and 1/(abac^2-abab*acac) are recomputed when needed)
     const uint32_t *gridBlock;
+    // the same 12-byte entries, indexed SPARSELY by (cx>>2) | (cy>>2)<<8 | (cz>>2)<<16 so that the byte offset of a cell's
+    // block is 3*(cell & 0xFCFCFC) for a cell packed cx | cy<<8 | cz<<16 (wf_trace_sorted_kernel); 50 MB of address
+    // space, the same 3 MiB of touched lines
+    const uint32_t *gridBlockSparse;
     const uint2 *cellRange;
     const float *pairRec;
     // materials
@@ -118,7 +122,8 @@ struct RtWavefront {
     // entries (DDA start state computed once), keyed by the PREDICTED number of cell visits (exact for rays that hit
     // nothing) and counting-sorted longest first, so that a wave holds rays of similar length and the longest walks of
     // the round start first.  cont[0] is the staging area, cont[1] the sorted array (no continuation passes in this mode).
-    uint32_t sortMode;         // 0: trace reads the sharded request queues directly; 1: setup -> scatter -> trace(sorted)
+    uint32_t sortMode;         // 0: trace reads the sharded request queues directly; 1: setup -> scatter -> wf_trace_kernel<SORTED>;
+                               // 2 (default): setup -> scatter -> wf_trace_sorted_kernel
     uint32_t lookAhead;        // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
     uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
     uint32_t *sortTotal;       // [1] entries in the sorted array

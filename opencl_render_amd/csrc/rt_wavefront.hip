@@ -85,6 +85,29 @@ __device__ __forceinline__ bool pair_test(const float4 *__restrict__ rec, V3 o, 
     return hit;
 }
 
+// The same test on a record that is already in registers, BRANCH-FREE: every lane computes both halves, and whether the
+// plane distance was in range only enters the final predicate.  Lanes for which the reference would not have computed the
+// second half (raytrace_opencl.c:143) discard it; for the others every operation and operand is the same, so t, l1, l2
+// are bit-identical.  With no branch between the four 16-byte loads and their uses the compiler issues them together
+// (one round trip per candidate instead of three dependent ones).
+__device__ __forceinline__ bool pair_test_flat(const float4 r0, const float4 r1, const float4 r2, const float4 r3, V3 o, V3 d, float tmin,
+                                               float tmax, uint32_t excluded, float &t, float &l1, float &l2)
+{
+    const uint32_t tri = __float_as_uint(r0.w);
+    const V3 a = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z);
+    const V3 ao = sub3(o, a);
+    t = -dot3(n, ao) / dot3(n, d);
+    const V3 ab = mk(r2.x, r2.y, r2.z), ac = mk(r3.x, r3.y, r3.z);
+    const float abab = r2.w, abac = dot3(ab, ac), acac = r3.w; // dot(ab,ac) as at raytrace_opencl.c:147
+    const float inv = 1.f / (abac * abac - abab * acac);
+    const V3 ap = sub3(along(o, t, d), a);
+    const float ap_ab = dot3(ap, ab);
+    const float ap_ac = dot3(ap, ac);
+    l1 = (abac * ap_ac - acac * ap_ab) * inv;
+    l2 = (abac * ap_ab - abab * ap_ac) * inv;
+    return (tri != excluded) & (tmin < t) & (t < tmax) & (0 <= l1) & (0 <= l2) & (l1 + l2 <= 1.f);
+}
+
 struct __attribute__((packed, aligned(4))) GridBlock { uint32_t lo, hi, rank; };
 
 #ifdef RT_DIAG_STAMPS
@@ -959,6 +982,252 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
     }
 }
 
+// ---- stage 3, lean variant for length-sorted input ------------------------------------------------------------------------
+// Same walk-then-test scheme and the same arithmetic per ray as wf_trace_kernel, stripped to what sorted input needs: no
+// visit budgets, no continuation queue, no in-workgroup compaction (waves already hold rays of similar length), waves of a
+// workgroup never synchronise after the plane table is staged.  The walk is VALU-issue bound (a round's waves outnumber the
+// wave slots), so the step is built to cost as few vector instructions as possible:
+//   * per-ray constants of the step are precomputed per axis (signed cell increment, plane-table offset, exit coordinate);
+//   * the occupancy word of a 4x4x4 block is found at byte offset 3*(cell & 0xFCFCFC) of a sparsely indexed copy of the
+//     block table (two instructions instead of six), its bit with one multiply (bit-gather) and one bit-field extract;
+//   * an occupied cell is recorded as its packed coordinates only; the dense cell id (rank + popcount) is worked out in the
+//     test phase, where all 64 lanes have an item, instead of in the walk, where 6 of 64 lanes are on an occupied cell.
+#ifndef RT_WF_LEAN_WAVES
+#define RT_WF_LEAN_WAVES 4
+#endif
+#ifndef RT_WF_LEAN_LIST
+#define RT_WF_LEAN_LIST 16            // per-lane LDS slots: recorded occupied cells + the cells logged by the current blind phase
+#endif
+#ifndef RT_WF_BLIND
+#define RT_WF_BLIND 8                 // cell visits per blind phase
+#endif
+#ifndef RT_WF_LEAN_STALL
+#define RT_WF_LEAN_STALL 64           // test once (lanes without room for another phase) x this exceeds the lanes still walking
+#endif
+__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_sorted_kernel(const RtDevScene S, const RtWavefront W)
+{
+    __shared__ float planes[3 * (RT_GRID_DIV + 1)];
+    __shared__ uint32_t cellList[RT_WF_LEAN_LIST][256];                 // [entry][thread] packed cells cx | cy<<8 | cz<<16
+    __shared__ uint8_t ownerOf[4][RT_WF_LEAN_LIST * 64];                // per wave: lane that recorded item c
+    __shared__ unsigned long long keyOf[4][64];                         // per wave and lane: (cell order, pair index) of the earliest hit
+
+    const uint32_t total = W.sortTotal[0];
+    const uint32_t local0 = blockIdx.x * 256;
+    if (local0 >= total) return; // whole workgroup beyond the entries
+    for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t mine = local0 + threadIdx.x;
+    bool active = mine < total;
+    uint32_t q = 0, excluded = RT_NONE, cell = 0, endCell = 0xffffffffu;
+    V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+    float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    if (active) {
+        const uint4 *e = W.cont[1] + 4 * (size_t)mine;
+        const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
+        q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
+        dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
+        o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
+        d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+    }
+    // per-axis step constants (:387-398): direction of travel is fixed per ray
+    const bool px = (0.f <= d.x), py = (0.f <= d.y), pz = (0.f <= d.z);
+    const uint32_t stepX = px ? 1u : (uint32_t)-1, stepY = py ? (1u << 8) : (uint32_t)-(1 << 8), stepZ = pz ? (1u << 16) : (uint32_t)-(1 << 16);
+    // byte offset into `planes` of the plane that bounds the NEW cell ahead: 4*(axisBase + c + (positive ? 1 : 0))
+    const uint32_t offX = 4u * (px ? 1u : 0u), offY = 4u * ((RT_GRID_DIV + 1) + (py ? 1u : 0u)), offZ = 4u * (2 * (RT_GRID_DIV + 1) + (pz ? 1u : 0u));
+    // coordinate at which a further step leaves the grid (:389,:393,:397), packed like the cell
+    const uint32_t lastCell = (px ? 255u : 0u) | ((py ? 255u : 0u) << 8) | ((pz ? 255u : 0u) << 16);
+    const char *__restrict__ blockTable = reinterpret_cast<const char *>(S.gridBlockSparse);
+    const char *planeBytes = reinterpret_cast<const char *>(planes);
+
+    uint32_t wordKey = 0xffffffffu, wordLo = 0, wordHi = 0; // occupancy word of the last block looked up (key = cell & 0xFCFCFC)
+    uint32_t listed = 0;
+    bool walkEnded = !active;
+    uint32_t spins = 0;
+#ifdef RT_DIAG_STAMPS
+    unsigned long long dgWalk = 0, dgTest = 0, dgWalkIters = 0, dgBatches = 0, dgSteps = 0, dgItems = 0;
+    const unsigned long long dgStart = diag_stamp();
+#endif
+
+#pragma unroll 1
+    for (;;) {
+        // ---- walk: BLIND phases of RT_WF_BLIND cell visits (pure DDA stepping, every visited cell logged in LDS), each
+        // followed by ONE batched look-up of the logged cells' occupancy words.  The look-ups of a phase are independent
+        // loads, so a wave waits for memory once per phase instead of once per visit.
+#ifdef RT_DIAG_STAMPS
+        const unsigned long long dgW0 = diag_stamp();
+#endif
+#pragma unroll 1
+        for (;;) {
+            const bool canWalk = !walkEnded && listed + RT_WF_BLIND <= RT_WF_LEAN_LIST;
+            const unsigned long long walkers = __ballot(canWalk);
+            if (walkers == 0ull) break;
+            const int stalled = __popcll(__ballot(!walkEnded && !canWalk));
+            if (stalled * RT_WF_LEAN_STALL > __popcll(walkers)) break;
+            if (++spins > RT_WF_SPIN_LIMIT) break; // cannot happen (a ray makes at most 766 visits); keeps a logic error from hanging the GPU
+#ifdef RT_DIAG_STAMPS
+            dgWalkIters++;
+#endif
+            uint32_t logged = 0;
+#pragma unroll
+            for (int u = 0; u < RT_WF_BLIND; ++u) {
+#ifdef RT_DIAG_STAMPS
+                dgSteps += (unsigned long long)__popcll(__ballot(canWalk && !walkEnded));
+#endif
+                if (canWalk && !walkEnded) {
+                    cellList[listed + logged][threadIdx.x] = cell;
+                    ++logged;
+                    // the end cell ends the walk after it has been visited (:380-381)
+                    bool done = (cell == endCell);
+                    if (!done) {
+                        // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
+                        const bool sxm = (dx < dy) & (dx < dz);
+                        const bool sym = !sxm & (dy < dz);
+                        const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);
+                        done = ((((cell ^ lastCell) >> shift) & 255u) == 0u); // the step would leave the grid
+                        if (!done) {
+                            cell += sxm ? stepX : (sym ? stepY : stepZ);
+                            const uint32_t off = sxm ? offX : (sym ? offY : offZ);
+                            const float plane = *reinterpret_cast<const float *>(planeBytes + (((cell >> shift) & 255u) << 2) + off);
+                            const float dd = sxm ? d.x : (sym ? d.y : d.z);
+                            const float oo = sxm ? o.x : (sym ? o.y : o.z);
+                            const float nd = (plane - oo) / dd;
+                            dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
+                        }
+                    }
+                    walkEnded = done;
+                }
+            }
+            // look-up: which of the logged cells are occupied?  Keep those, in path order, at the front of the list.
+            uint32_t lc[RT_WF_BLIND], lkey[RT_WF_BLIND];
+            uint2 lw[RT_WF_BLIND];
+            bool lneed[RT_WF_BLIND];
+            {
+                uint32_t prev = wordKey;
+#pragma unroll
+                for (int i = 0; i < RT_WF_BLIND; ++i) {
+                    lc[i] = ((uint32_t)i < logged) ? cellList[listed + i][threadIdx.x] : 0u;
+                    lkey[i] = lc[i] & 0xFCFCFCu;
+                    lneed[i] = ((uint32_t)i < logged) && lkey[i] != prev;
+                    lw[i] = make_uint2(0u, 0u);
+                    if (lneed[i]) { lw[i] = *reinterpret_cast<const uint2 *>(blockTable + (size_t)(lkey[i] * 3u)); prev = lkey[i]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RT_WF_BLIND; ++i) {
+                if ((uint32_t)i < logged) {
+                    if (lneed[i]) { wordKey = lkey[i]; wordLo = lw[i].x; wordHi = lw[i].y; }
+                    // bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 : gather the three 2-bit fields with one multiply
+                    const uint32_t bit = (((lc[i] & 0x030303u) * 0x1041u) >> 12) & 63u;
+                    const uint32_t half = (lc[i] & 0x20000u) ? wordHi : wordLo; // bit 5 of `bit` is bit 1 of cz
+                    if ((half >> (bit & 31u)) & 1u) {
+                        cellList[listed][threadIdx.x] = lc[i];
+                        ++listed;
+                    }
+                }
+            }
+        }
+
+#ifdef RT_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long dgT0 = diag_stamp();
+        dgWalk += dgT0 - dgW0;
+        dgBatches++;
+#endif
+        // ---- test, wave-cooperative (see wf_trace_kernel): items = recorded cells of the whole wave, one per lane and round
+        {
+            const uint32_t mineN = listed;
+            uint32_t incl = mineN;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if ((int)lane >= off) incl += up;
+            }
+            const uint32_t myBase = incl - mineN;
+            const uint32_t items = __shfl(incl, 63, 64);
+#ifdef RT_DIAG_STAMPS
+            dgItems += items;
+#endif
+            if (items) { // wave-uniform
+                volatile uint8_t *owners = ownerOf[wave];
+                volatile unsigned long long *keys = keyOf[wave];
+                for (uint32_t j = 0; j < mineN; ++j) owners[myBase + j] = (uint8_t)lane;
+                keys[lane] = ~0ull;
+                __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
+                for (uint32_t c0 = 0; c0 < items; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    const bool has = c < items;
+                    const uint32_t owner = has ? owners[c] : 0u;
+                    const uint32_t ownerBase = __shfl(myBase, owner, 64);
+                    const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+                    const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+                    const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64);
+                    const uint32_t pexcl = __shfl(excluded, owner, 64);
+                    if (has) {
+                        const uint32_t j = c - ownerBase;
+                        const uint32_t pc = cellList[j][(wave << 6) + owner];
+                        // dense cell id = rank of the block + occupied cells below this one in the block
+                        const uint32_t *gb = reinterpret_cast<const uint32_t *>(blockTable + (size_t)((pc & 0xFCFCFCu) * 3u));
+                        const uint32_t lo32 = gb[0], hi32 = gb[1], rank = gb[2];
+                        const uint32_t bit = (pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u);
+                        const unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;
+                        const uint32_t dense = rank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+                        const uint2 range = S.cellRange[dense];
+                        uint32_t bestPair = RT_NONE;
+                        float tbest = ptmax; // running maximum, reset per cell (:366)
+                        // software pipeline: the next candidate's record is requested before the current one is tested
+                        const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)range.x;
+                        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+                        if (range.x < range.y) { r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+                        for (uint32_t i = range.x; i < range.y; ++i) {
+                            float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3;
+                            if (i + 1 < range.y) { n0 = rec[4]; n1 = rec[5]; n2 = rec[6]; n3 = rec[7]; }
+                            rec += 4;
+                            float t, l1, l2;
+                            if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, tbest, pexcl, t, l1, l2)) {
+                                bestPair = i; tbest = t;
+                            }
+                            r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+                        }
+                        if (bestPair != RT_NONE)
+                            atomicMin((unsigned long long *)&keys[owner], ((unsigned long long)j << 32) | (unsigned long long)bestPair);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mineN) {
+                    const unsigned long long key = keys[lane];
+                    if (key != ~0ull) { // the owner re-evaluates the winning pair: t, l1, l2 bit for bit
+                        uint32_t tri;
+                        float t, l1, l2;
+                        pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key, o, d, tmin, tmax, excluded, tri, t, l1, l2);
+                        W.res[q] = make_uint4(tri, __float_as_uint(t), __float_as_uint(l1), __float_as_uint(l2));
+                        active = false;
+                        walkEnded = true;
+                    }
+                }
+            }
+            listed = 0;
+        }
+#ifdef RT_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dgTest += diag_stamp() - dgT0;
+#endif
+        if (active && walkEnded) { // walked to the end without a hit
+            W.res[q] = make_uint4(RT_NONE, __float_as_uint(tmax), 0u, 0u);
+            active = false;
+        }
+        if (spins > RT_WF_SPIN_LIMIT || __ballot(active) == 0ull) break;
+    }
+#ifdef RT_DIAG_STAMPS
+    if (lane == 0) { // cycle anatomy of this wave (scripts/diag_stamps.py)
+        atomicAdd(&S.stats[0], diag_stamp() - dgStart); atomicAdd(&S.stats[1], dgWalk); atomicAdd(&S.stats[2], dgTest);
+        atomicAdd(&S.stats[3], dgWalkIters); atomicAdd(&S.stats[4], dgBatches); atomicAdd(&S.stats[5], dgSteps);
+        atomicAdd(&S.stats[6], 1ull); atomicAdd(&S.stats[7], dgItems);
+    }
+#endif
+}
+
 // ---- stage 4: samples -> u16 planes -----------------------------------------------------------------------------------
 // One thread per pixel of the instance's tiles, row-major inside the tile (coalesced 2-byte stores).  Samples are added
 // in order, each addend truncated on its own, saturating (raytrace_opencl.c:726-741); `first` starts from zero, later
@@ -1003,7 +1272,8 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
 extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
                                        uint32_t blocks, hipStream_t stream)
 {
-    if (pass == 0 && wf->sortMode) hipLaunchKernelGGL(wf_trace_kernel<TRACE_SORTED>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
+    if (pass == 0 && wf->sortMode == 2) hipLaunchKernelGGL(wf_trace_sorted_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf);
+    else if (pass == 0 && wf->sortMode) hipLaunchKernelGGL(wf_trace_kernel<TRACE_SORTED>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
     else if (pass == 0) hipLaunchKernelGGL(wf_trace_kernel<TRACE_FRESH>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
     else hipLaunchKernelGGL(wf_trace_kernel<TRACE_CONT>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
     return hipGetLastError();
