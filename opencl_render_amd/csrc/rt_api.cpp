@@ -31,8 +31,7 @@ extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *til
 
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
-                                       uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
 extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
 
@@ -74,7 +73,6 @@ struct rtHipScene {
     int pipeline = RT_HIP_PIPELINE_WAVEFRONT;
     RtWavefront wf{};
     uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
-    uint32_t passCount = 1, passBudget[RT_WF_PASSES] = { 0xffffffffu }; // one unbounded pass measured best (1080p and 4K)
     uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum, sort]
     struct StageEvent { int stage; hipEvent_t a, b; };
@@ -364,7 +362,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, sc->device));
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-        const uint64_t perPath = 8 + 16 + 16 + 48 + 10 * 16 + (uint64_t)RT_RING * 48 + 8 + 16 + 2 * (2 * 40 + 16 + 2 * 64) + 16;
+        // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
+        // result, staging + sorted entry
+        const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 16 + 4 + 2 * (2 * 40 + 16 + 2 * 64) + 16;
         uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
         if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
@@ -375,51 +375,32 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         const uint64_t primaryBlocks = (uint64_t)nt * 64 * sb;
         const uint64_t shardCap = ((primaryBlocks + RT_WF_SHARDS - 1) / RT_WF_SHARDS) * 256;
         const uint64_t cap = shardCap * RT_WF_SHARDS;
-        if (cap > 0xfffffff0ull) return fail("tile set too large for one batch");
+        if (cap > 0x7ffffff0ull) return fail("tile set too large for one batch");
         RtWavefront &Wf = sc->wf;
         Wf.capacity = (uint32_t)cap;
         Wf.shardCap = (uint32_t)shardCap;
-        Wf.queueStride = (uint32_t)(2 * shardCap);
-        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path
+        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
+        const bool multiLight = d->lightCount > 1;
         Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
         if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
-            sc->alloc<float4>(cap, &Wf.cur0) || sc->alloc<float4>(cap, &Wf.cur1) || sc->alloc<float4>(cap, &Wf.cur2) ||
-            sc->alloc<float4>(cap, &Wf.shN) || sc->alloc<float4>(cap, &Wf.shWhere) || sc->alloc<float4>(cap, &Wf.shF0) ||
-            sc->alloc<float4>(cap, &Wf.shF1) || sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(cap, &Wf.shToL) ||
-            sc->alloc<float4>(cap, &Wf.shTex) || sc->alloc<float4>(cap, &Wf.shTransp) || sc->alloc<float4>(cap, &Wf.shRefl) ||
-            sc->alloc<float4>(cap, &Wf.shLum) || sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) ||
-            sc->alloc<unsigned long long>(cap, &Wf.rngL) || sc->alloc<uint4>(cap, &Wf.laRes) ||
+            sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
+            sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
+            sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<uint4>(cap, &Wf.laRes) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
             sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
             sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
             sc->alloc<uint4>(qcap, &Wf.res) || sc->alloc<float4>(pix * sb, &Wf.sampleOut) ||
-            sc->alloc<uint4>(qcap * 4, &Wf.cont[0]) || sc->alloc<uint4>(qcap * 4, &Wf.cont[1]) ||
-            sc->alloc<uint32_t>((uint64_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, &Wf.counts) ||
+            sc->alloc<uint4>(qcap * 4, &Wf.stageEnt) || sc->alloc<uint4>(qcap * 4, &Wf.sortedEnt) ||
+            sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
             sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(1, &Wf.sortTotal))
             return -1;
         HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
-        Wf.sortMode = 2;  // length-sorted trace input + lean trace kernel (RT_WF_SORT=0: request queues directly, 1: sorted + general kernel)
         Wf.lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
-        if (const char *b = getenv("RT_WF_SORT")) Wf.sortMode = (b[0] >= '0' && b[0] <= '2') ? (uint32_t)(b[0] - '0') : 2u;
         if (const char *b = getenv("RT_WF_LOOKAHEAD")) Wf.lookAhead = (b[0] != '0') ? 1u : 0u;
-        Wf.contCounts = Wf.counts + 3 * RT_WF_SHARDS;
         HIP_OK(hipHostMalloc((void **)&sc->hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
         sc->traceBlocks = (uint32_t)(qcap / 256);  // one workgroup per 256 entries of every queue slice; surplus groups exit at once
-        (void)cus;
-        sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((qcap + 255) / 256));
+        sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
         if (sc->logicBlocks == 0) sc->logicBlocks = 1;
-        if (const char *b = getenv("RT_WF_BUDGETS")) { // tuning aid: comma-separated cell-visit budgets; a final unbounded pass is appended
-            uint32_t n = 0;
-            while (*b && n < RT_WF_PASSES - 1) {
-                char *endp = nullptr;
-                const unsigned long v = strtoul(b, &endp, 10);
-                if (endp == b) break;
-                sc->passBudget[n++] = (uint32_t)(((v ? v : 1) + 1023) / 1024 * 1024); // multiples of the trace kernel's epoch (RT_WF_EPOCH)
-                b = (*endp == ',') ? endp + 1 : endp;
-            }
-            sc->passBudget[n++] = 0xffffffffu;
-            sc->passCount = n;
-        }
         const char *env = getenv("RT_HIP_PIPELINE");
         if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     }
@@ -455,19 +436,23 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
     for (uint32_t base = 0; base < D.sampleCount; base += sc->samplesPerBatch) {
         Wf.sampleBase = base;
         Wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, D.sampleCount - base);
-        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * (size_t)(3 + RT_WF_PASSES) * RT_WF_SHARDS, st));
+        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_QSHARDS, st));
         HIP_OK(stage(0, [&] { return rtw_launch_primary(&D, &Wf, st); }));
         uint32_t r = 0;
         for (;;) {
-            const uint32_t chunk = 4;
+            // Rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds
+            // (shade the primary hits | consume shadow + bounce answers, shade the bounce hits | consume their shadow
+            // answers) with a trace after the first two, so the first chunk is 3 rounds; the trace after a chunk's last
+            // logic round is only issued once the host has seen that rays are waiting.
+            const uint32_t chunk = 3;
             for (uint32_t k = 0; k < chunk && r < RT_WF_MAX_ROUNDS; ++k, ++r) {
+                if (r > 0) { // the requests appended by logic(r-1): sort by predicted walk length, then walk the grid
+                    HIP_OK(stage(4, [&] { return rtw_launch_sort(&D, &Wf, r, sc->traceBlocks, st); }));
+                    HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, sc->traceBlocks, st); }));
+                }
                 HIP_OK(stage(1, [&] { return rtw_launch_logic(&D, &Wf, r, sc->logicBlocks, st); }));
-                if (Wf.sortMode) HIP_OK(stage(4, [&] { return rtw_launch_sort(&D, &Wf, r + 1, sc->traceBlocks, st); }));
-                // cell-visit budgets per pass: a walk has at most 766 visits; the last pass is unbounded
-                for (uint32_t p = 0; p < sc->passCount; ++p)
-                    HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, r + 1, p, sc->passBudget[p], sc->traceBlocks, st); }));
             }
-            HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + (r % 3) * RT_WF_SHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + (r % 3) * RT_WF_QSHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, st)); // main slices
             HIP_OK(hipStreamSynchronize(st));
             uint64_t waiting = 0;
             for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += sc->hostCount[i];

@@ -79,52 +79,49 @@ struct RtDevScene {
 // ---- wavefront pipeline buffers (rt_wavefront.hip) -------------------------------------------------------------------
 // A "path" is one sample of one pixel whose primary ray hit something; it gets a dense id `a` (allocated by the
 // primary stage) and lives in HBM between stages as structure-of-arrays state.  Rays that need the grid are appended
-// to a request queue; a persistent trace kernel consumes the queue with every lane busy (idle lanes refill from it).
-//   round r:   logic(r)  reads  req[r&1].path + res[q]   for q < counts[r]      -> appends to req[(r+1)&1], counts[r+1]
-//              trace(r+1) reads req[(r+1)&1][q]           for q < counts[r+1]    -> writes res[q]
+// to a request queue.
+//   round r:   logic(r)   reads  req[r&1][q].path + res[q]  for the entries of counts[r%3]   -> appends to req[(r+1)&1], counts[(r+1)%3]
+//              sort(r+1)  turns the new requests into self-contained entries, longest predicted walk first
+//              trace(r+1) walks the grid for every entry                                      -> writes res[q]
 #define RT_WF_MAX_ROUNDS 100000
-#define RT_WF_SHARDS 256      // every queue is cut into this many independent slices, each with its own counter
-#define RT_WF_PASSES 8        // at most this many trace passes per round; the last one runs every ray to its end
+#define RT_WF_SHARDS 256      // paths are born into one of this many shards (primary workgroup % RT_WF_SHARDS)
+#define RT_WF_QSHARDS (2 * RT_WF_SHARDS) // queue slices: [0,SHARDS) main requests (one per waiting path), [SHARDS,2*SHARDS) look-ahead requests
 #define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input: bin = (767 - predicted visits) / 12, 0 = longest
 #define RT_WF_SORT_COPIES 4   // independent histograms (workgroup % copies) to spread the atomics
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
     uint32_t samplesInBatch;
+    uint32_t lookAhead;      // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
     // per-path state, indexed by path id
-    unsigned long long *rng; // generator state (raytrace_opencl.c:474-481)
-    unsigned long long *rngL; // second cursor into the same stream: where the CURRENT hit's light set-ups draw from (the
-                             // main cursor has already been moved past all draws of that hit when its spawns were computed)
-    uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel
-                             // z: head | tail<<4 | stage<<8 | lookahead state<<10 | lookahead ring index<<12 | light<<16   w: hit triangle
+    unsigned long long *rng; // generator state (raytrace_opencl.c:474-481), already moved past the current hit's light draws
+    unsigned long long *rngL; // lightCount > 1 only: where the current hit's NEXT light set-up draws from
+    uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel  w: hit triangle
+                             // z: head | tail<<4 | stage<<8 | attenuation stored<<9 | look-ahead state<<10 | look-ahead ring index<<12 | light<<16
     uint4 *laRes;            // answer of the path's look-ahead ray while it waits to be consumed
-    float4 *outc;            // accumulated colour xyz, w: hit distance
-    float4 *cur0, *cur1, *cur2; // ray in flight: o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera
-    float4 *shN, *shWhere, *shF0, *shF1, *shAtt, *shToL; // n.xyz,l1 | where.xyz,l2 | face0.xyz,lmin | face1.xyz,lmax | atten | toLight
-    float4 *shTex, *shTransp, *shRefl, *shLum;           // the hit's channel texels
-    float4 *ring;            // [capacity][12][3] queued rays, same packing as cur0..2
-    // ray requests / results
+    uint32_t *laSlot;        // queue index of the look-ahead request issued last round
+    float4 *outc;            // accumulated colour xyz
+    float4 *ring;            // [capacity][12][3] the pixel's ray queue (:459-468): o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera;
+                             // slot `head` is the ray in flight
+    // what a hit still needs once its spawns are made and a shadow ray is in flight (everything else was folded at shading time):
+    float4 *shP;             // P.xyz = (1-out)*weight*(1-transparency)*texture, the factors of :649-651 in the reference's order; w: N.L of this light
+    float4 *shFace;          // xyz: the face[] entry that :647 will select (the other one is dead); w: 1 if front facing
+    float4 *shAtt;           // shadow attenuation so far (only once a transparent occluder was met, :616-625)
+    float4 *shN, *shWhere;   // lightCount > 1 only: shading normal and hit point for the next light's set-up
+    // ray requests / results.  Queue slice s holds entries [s*shardCap, s*shardCap + counts[s]); a path born into shard s appends
+    // its main requests to slice s and its look-ahead requests to slice RT_WF_SHARDS+s, so appends hit 512 different counters (a
+    // single address sustains only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shard.
     float4 *reqO[2], *reqD[2]; // o.xyz,tmin | d.xyz,tmax
-    uint2 *reqX[2];            // excluded triangle, path id | (1u<<31 for the look-ahead request, which sits right after its path's main request)
+    uint2 *reqX[2];            // excluded triangle, path id
     uint4 *res;                // hit triangle (0xffffffff = none), t, l1, l2 (float bits)
-    // Queues are SHARDED: a path is born into shard (primary workgroup % RT_WF_SHARDS) and everything it ever emits --
-    // ray requests, continuation entries -- goes to the same shard's slice [shard*shardCap, (shard+1)*shardCap) of the
-    // queue arrays.  Appends therefore hit RT_WF_SHARDS different counters instead of one (a single address sustains
-    // only ~90 atomics/us, which was the whole cost of the primary and logic kernels), and a slice can never overflow:
-    // it holds at most the paths born into it.  Counters are small rings zeroed in-stream by the logic kernel.
-    uint32_t shardCap;         // PATHS per shard (multiple of 256): path-state arrays hold RT_WF_SHARDS*shardCap entries
-    uint32_t queueStride;      // queue ENTRIES per shard = 2*shardCap: a path may have two rays in flight (its hit's shadow
-                               // ray and a look-ahead trace of the next ring entry); req*/res/cont arrays use this stride
-    uint32_t *counts;          // [3][RT_WF_SHARDS] fresh-request queue length; round r reads [r%3], appends to [(r+1)%3]
-    uint32_t *contCounts;      // [RT_WF_PASSES][RT_WF_SHARDS] continuation entries appended by each trace pass
-    uint4 *cont[2];            // [capacity][4], self-contained: {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz,-}
-    // Length-sorted trace input (wf_setup_kernel / wf_scatter_kernel): a round's requests are turned into self-contained
-    // entries (DDA start state computed once), keyed by the PREDICTED number of cell visits (exact for rays that hit
-    // nothing) and counting-sorted longest first, so that a wave holds rays of similar length and the longest walks of
-    // the round start first.  cont[0] is the staging area, cont[1] the sorted array (no continuation passes in this mode).
-    uint32_t sortMode;         // 0: trace reads the sharded request queues directly; 1: setup -> scatter -> wf_trace_kernel<SORTED>;
-                               // 2 (default): setup -> scatter -> wf_trace_sorted_kernel
-    uint32_t lookAhead;        // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
+    uint32_t shardCap;         // entries per queue slice = paths per shard (multiple of 256)
+    uint32_t *counts;          // [3][RT_WF_QSHARDS] queue lengths; round r reads [r%3], appends to [(r+1)%3]; zeroed in-stream by the logic kernel
+    // Length-sorted trace input (wf_setup_kernel / wf_scatter_kernel): a round's requests become self-contained 64-byte entries
+    // {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz,-} (DDA start state computed once), keyed by the PREDICTED
+    // number of cell visits (exact for rays that hit nothing) and counting-sorted longest first, so that a wave holds rays of
+    // similar length and the longest walks of the round start first.
+    uint4 *stageEnt;           // [2*capacity][4] entries in queue order, tagged with (bin, copy, rank)
+    uint4 *sortedEnt;          // [2*capacity][4] entries in sorted order
     uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
     uint32_t *sortTotal;       // [1] entries in the sorted array
     float4 *sampleOut;         // [capacity] finished colour per output slot

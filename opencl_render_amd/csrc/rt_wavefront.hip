@@ -2,16 +2,16 @@
 //
 // Why: in a one-thread-per-pixel kernel only the pixels whose primary ray hit something (28 % in the headline scene)
 // do any secondary work, and their grid walks differ in length by 10x, so a wave averages 4-5 busy lanes of 64
-// (rocprofv3 PMC, profiles/r01_v1_*).  Here every ray that needs the grid becomes a queue entry, and a persistent
-// trace kernel walks the grid with all 64 lanes busy: a lane that finishes its ray pulls the next one.
+// (rocprofv3 PMC, profiles/r01_v1_*).  Here every ray that needs the grid becomes a queue entry.
 //
 //   wf_primary  one thread per (pixel, sample): jittered camera ray + per-pixel candidate list (raytrace_opencl.c:470-528).
 //               Hits become PATHS: dense id from a wave-aggregated atomic, state written to HBM (rt_device.h).
-//   wf_logic    one thread per live path: resumes the per-sample state machine of raytrace_opencl.c:532-724 where it
+//   wf_logic    one thread per waiting path: resumes the per-sample state machine of raytrace_opencl.c:532-724 where it
 //               stopped, runs it until the next grid ray (shadow ray :611, or a queued ray :530) and appends that ray
 //               to the next round's queue; paths with an empty ring retire their colour.
-//   wf_trace    persistent waves; each lane owns one queued ray and walks the non-uniform grid (:324-401) one cell per
-//               iteration; finished lanes refill from the queue (ballot + one atomic per wave).
+//   wf_setup / wf_scatter   turn the round's requests into self-contained entries sorted by predicted walk length.
+//   wf_trace    one entry per lane: walks the non-uniform grid (:324-401) in blind phases, tests the occupied cells it
+//               passed wave-cooperatively.
 //   wf_accum    per pixel, samples in order: truncated saturating u16 accumulate into the tile buffer (:726-741).
 //
 // Per path everything happens in the reference's order (RNG draws, ring FIFO, light loop), and paths never interact,
@@ -58,34 +58,9 @@ __device__ __forceinline__ uint32_t camera_scan(const RtDevScene &S, uint32_t lo
     return hit_tri;
 }
 
-// Triangle test against a (cell, triangle) pair record (rt_device.h): same arithmetic as tri_test / the reference
-// (raytrace_opencl.c:124-172), two 16-byte loads for the plane test, two more only when t is in range.
-__device__ __forceinline__ bool pair_test(const float4 *__restrict__ rec, V3 o, V3 d, float tmin, float tmax, uint32_t excluded,
-                                          uint32_t &tri, float &t, float &l1, float &l2)
-{
-    // all four quads are requested together: one round trip per candidate instead of two dependent ones
-    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-    tri = __float_as_uint(r0.w);
-    if (tri == excluded) return false;
-    const V3 a = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z);
-    const V3 ao = sub3(o, a);
-    t = -dot3(n, ao) / dot3(n, d);
-    bool hit = false;
-    if (tmin < t && t < tmax) {
-        const V3 ab = mk(r2.x, r2.y, r2.z), ac = mk(r3.x, r3.y, r3.z);
-        const float abab = r2.w, abac = dot3(ab, ac), acac = r3.w; // dot(ab,ac) as at raytrace_opencl.c:147
-        const float inv = 1.f / (abac * abac - abab * acac);
-        const V3 ap = sub3(along(o, t, d), a);
-        const float ap_ab = dot3(ap, ab);
-        const float ap_ac = dot3(ap, ac);
-        l1 = (abac * ap_ac - acac * ap_ab) * inv;
-        l2 = (abac * ap_ab - abab * ap_ac) * inv;
-        hit = (0 <= l1 && 0 <= l2 && l1 + l2 <= 1.f);
-    }
-    return hit;
-}
-
-// The same test on a record that is already in registers, BRANCH-FREE: every lane computes both halves, and whether the
+// Triangle test against a (cell, triangle) pair record (rt_device.h: {a,id}{n,-}{ab,abab}{ac,acac}), the arithmetic of
+// tri_test / the reference (raytrace_opencl.c:124-172).
+// The record is already in registers and the test is BRANCH-FREE: every lane computes both halves, and whether the
 // plane distance was in range only enters the final predicate.  Lanes for which the reference would not have computed the
 // second half (raytrace_opencl.c:143) discard it; for the others every operation and operand is the same, so t, l1, l2
 // are bit-identical.  With no branch between the four 16-byte loads and their uses the compiler issues them together
@@ -108,8 +83,6 @@ __device__ __forceinline__ bool pair_test_flat(const float4 r0, const float4 r1,
     return (tri != excluded) & (tmin < t) & (t < tmax) & (0 <= l1) & (0 <= l2) & (l1 + l2 <= 1.f);
 }
 
-struct __attribute__((packed, aligned(4))) GridBlock { uint32_t lo, hi, rank; };
-
 #ifdef RT_DIAG_STAMPS
 // Diagnostic build only (never shipped, outputs untouched): shader-clock stamps, summed per wave into S.stats.
 __device__ __forceinline__ unsigned long long diag_stamp()
@@ -119,6 +92,27 @@ __device__ __forceinline__ unsigned long long diag_stamp()
     return t;
 }
 #endif
+
+// GetSpherePoint (raytrace_opencl.c:30-45) split in two: the draws, and the scaling by the sphere's radius.  The number of
+// draws does not depend on the radius, so a hit's light samples can be drawn before the radius is looked at.
+struct SphereRaw { V3 p; float len, sq; };
+__device__ SphereRaw sphere_raw(uint64_t &s)
+{
+    SphereRaw r;
+    do {
+        r.p.x = rand11(s);
+        r.p.y = rand11(s);
+        r.p.z = rand11(s);
+        r.len = sqrt_rn(dot3(r.p, r.p));
+    } while (r.len <= 0.f);
+    r.sq = sqrt_rn(rand01(s));
+    return r;
+}
+__device__ __forceinline__ V3 sphere_scaled(const SphereRaw &r, float radius)
+{
+    const float scale = r.sq * radius / r.len; // :40
+    return mk(scale * r.p.x, scale * r.p.y, scale * r.p.z);
+}
 
 } // namespace
 
@@ -157,18 +151,18 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
     const bool born = valid && hit_tri != RT_NONE;
     // workgroups are dealt to the shards round-robin: concurrently running groups append to different counters
     const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) % RT_WF_SHARDS;
-    const uint32_t slot0 = wave_append(&W.counts[shard], born); // round 0 uses ring slot 0
-    const uint32_t a = shard * W.shardCap + slot0;    // path id
-    const uint32_t q0 = shard * W.queueStride + slot0; // its round-0 queue entry: the primary hit plays the answered request
+    // the path id doubles as the index of its round-0 queue entry: the primary hit plays the answered request
+    const uint32_t a = shard * W.shardCap + wave_append(&W.counts[shard], born);
     if (born) {
         W.rng[a] = rng;
         W.meta[a] = make_uint4(outSlot, localPixel, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), hit_tri);
-        W.outc[a] = make_float4(0.f, 0.f, 0.f, hit_t);
-        W.cur0[a] = pack4(ld3(S.eye), 0.f);
-        W.cur1[a] = pack4(dir, __uint_as_float(RT_NONE));
-        W.cur2[a] = make_float4(1.f, 1.f, 1.f, __uint_as_float((12u << 1) | 1u)); // maxBounces 12, fromCamera (:492,:505)
-        W.reqX[0][q0] = make_uint2(RT_NONE, a);
-        W.res[q0] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
+        W.outc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 *ringA = W.ring + (size_t)a * (RT_RING * 3); // ring slot 0 = the camera ray (:490-508)
+        ringA[0] = pack4(ld3(S.eye), 0.f);
+        ringA[1] = pack4(dir, __uint_as_float(RT_NONE));
+        ringA[2] = make_float4(1.f, 1.f, 1.f, __uint_as_float((12u << 1) | 1u)); // maxBounces 12, fromCamera (:492,:505)
+        W.reqX[0][a] = make_uint2(RT_NONE, a);
+        W.res[a] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
     }
 }
 
@@ -177,10 +171,14 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 // LOOK-AHEAD trace of the next ring entry.  That is legal because nothing about a spawned ray depends on the shadow
 // rays of the hit that spawned it -- only the ORDER in which colour is accumulated does, and that order is kept: the
 // machine below is still strictly sequential per path, it merely finds some answers already there.  To know the spawned
-// rays before the light loop has run, a hit's spawns are computed when it is shaded: the main generator cursor is moved
-// past the light loop's draws (their count depends on the generator alone) to make the diffuse draw (:671), and a second
-// cursor (rngL) replays the light draws when each light is actually set up.  The draw order of raytrace_opencl.c is
-// unchanged, so are the results.
+// rays before the light loop has run, a hit's spawns are computed when it is shaded: the generator is moved past the light
+// loop's draws first (their count depends on the generator alone, :30-45), the diffuse direction is drawn (:671), and the
+// lights are set up later from the draws made on the way (light 0) or from a second cursor into the stream (rngL, further
+// lights).  The draw order of raytrace_opencl.c is unchanged, so are the results.
+//
+// What a hit keeps while its shadow rays are out is folded to two vectors: `out` already holds the luminance term (:642-644,
+// nothing touches `out` between a hit's shading and its :647-651), P is the product (1-out)*weight*(1-transparency)*texture
+// of :649-651 in the reference's order, and of face[2] only the entry :647 will pick is tracked.
 #ifndef RT_WF_LOGIC_WAVES
 #define RT_WF_LOGIC_WAVES 2
 #endif
@@ -191,95 +189,100 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
     __syncthreads();
 
     const uint32_t in = round & 1, outq = in ^ 1;
-    const uint32_t *countIn = W.counts + (round % 3) * RT_WF_SHARDS;
-    uint32_t *countOut = W.counts + ((round + 1) % 3) * RT_WF_SHARDS;
+    const uint32_t *countIn = W.counts + (round % 3) * RT_WF_QSHARDS;
+    uint32_t *countOut = W.counts + ((round + 1) % 3) * RT_WF_QSHARDS;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t waveId = (blockIdx.x * 256 + threadIdx.x) >> 6, waves = (gridDim.x * 256) >> 6;
     Counters cn; // unused (COUNT=false instantiations below)
-    // in-stream housekeeping: the ring slot two rounds ahead and the continuation counters of the coming trace passes
+    // in-stream housekeeping: the queue counters two rounds ahead and the histogram of this round's sort
     {
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-        if (gid < RT_WF_SHARDS) W.counts[((round + 2) % 3) * RT_WF_SHARDS + gid] = 0u;
-        if (gid < RT_WF_PASSES * RT_WF_SHARDS) W.contCounts[gid] = 0u;
-        if (gid < RT_WF_SORT_COPIES * RT_WF_SORT_BINS) W.sortHist[gid] = 0u; // filled by this round's wf_setup_kernel
+        if (gid < RT_WF_QSHARDS) W.counts[((round + 2) % 3) * RT_WF_QSHARDS + gid] = 0u;
+        if (gid < RT_WF_SORT_COPIES * RT_WF_SORT_BINS) W.sortHist[gid] = 0u;
     }
+    const bool multiLight = S.lightCount > 1u;
 
-    const uint32_t chunksPerShard = W.queueStride >> 6;
+    // main requests only (slices [0, RT_WF_SHARDS)): one per waiting path; look-ahead answers are picked up by index
+    const uint32_t chunksPerShard = W.shardCap >> 6;
     for (uint32_t chunk = waveId; chunk < RT_WF_SHARDS * chunksPerShard; chunk += waves) {
         const uint32_t shard = chunk / chunksPerShard;
         const uint32_t total = countIn[shard];
         const uint32_t local = (chunk - shard * chunksPerShard) * 64 + lane;
         if ((chunk - shard * chunksPerShard) * 64 >= total) continue; // wave-uniform
-        const uint32_t q = shard * W.queueStride + local;
-        bool live = local < total;
+        const uint32_t q = shard * W.shardCap + local;
+        const bool live = local < total;
         bool emit = false, emitLa = false;
         V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), lo3 = mk(0, 0, 0), ld3v = mk(0, 0, 0);
         float rtmin = 0.f, rtmax = 0.f, latmin = 0.f;
         uint32_t rexcl = RT_NONE, laexcl = RT_NONE, a = 0;
 
         if (live) {
-            const uint2 rx = W.reqX[in][q];
-            if (rx.y & 0x80000000u) live = false; // a look-ahead request: its path is driven from the entry before it
-            a = rx.y & 0x7fffffffu;
-        }
-        if (live) {
+            a = W.reqX[in][q].y;
             const uint4 r = W.res[q];
             uint32_t res_tri = r.x;
             float res_t = __uint_as_float(r.y), res_l1 = __uint_as_float(r.z), res_l2 = __uint_as_float(r.w);
 
             uint64_t rng = W.rng[a];
-            uint4 meta = W.meta[a];
-            const float4 oc = W.outc[a];
-            V3 out = xyz(oc);
-            float hit_t = oc.w;
+            const uint4 meta = W.meta[a];
+            V3 out = xyz(W.outc[a]);
             uint32_t hit_tri = meta.w;
             int head = (int)(meta.z & 15u), tail = (int)((meta.z >> 4) & 15u);
-            const uint32_t stage = (meta.z >> 8) & 3u;
-            uint32_t laState = (meta.z >> 10) & 3u; // 0 none, 1 requested last round (answer at q+1), 2 answer kept in laRes
+            const uint32_t stage = (meta.z >> 8) & 1u;
+            bool attStored = ((meta.z >> 9) & 1u) != 0u;
+            uint32_t laState = (meta.z >> 10) & 3u; // 0 none, 1 requested last round (answer at res[laSlot]), 2 answer kept in laRes
             int laIndex = (int)((meta.z >> 12) & 15u);
             uint32_t j = meta.z >> 16;
+            float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
             uint4 laAns = make_uint4(RT_NONE, 0u, 0u, 0u);
-            if (laState == 1u) { laAns = W.res[q + 1]; laState = 2u; }
+            bool laFetched = false;
+            if (laState == 1u) { laAns = W.res[W.laSlot[a]]; laState = 2u; laFetched = true; }
             else if (laState == 2u) laAns = W.laRes[a];
-            float4 c0 = W.cur0[a], c1 = W.cur1[a], c2 = W.cur2[a];
-            V3 cur_o = xyz(c0), cur_d = xyz(c1), cur_w = xyz(c2);
-            float cur_tmin = c0.w;
-            uint32_t cur_excl = __float_as_uint(c1.w);
-            int cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
-            int cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
 
-            // shading state (valid between SHADE_BEGIN and SHADE_END)
-            V3 n = mk(0, 0, 0), where = mk(0, 0, 0), face0 = mk(0, 0, 0), face1 = mk(0, 0, 0), atten = mk(0, 0, 0), toL = mk(0, 0, 0);
-            V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
-            float hit_l1 = 0.f, hit_l2 = 0.f, lmin = 0.f, lmax = 0.f;
+            // the ray in flight (ring slot `head`), loaded when its answer is here
+            V3 cur_o = mk(0, 0, 0), cur_d = mk(0, 0, 0), cur_w = mk(0, 0, 0);
+            float cur_tmin = 0.f;
+            uint32_t cur_excl = RT_NONE;
+            int cur_bounces = 0, cur_fromCamera = 0;
+            // the hit being lit
+            V3 n = mk(0, 0, 0), where = mk(0, 0, 0), P = mk(0, 0, 0), face = mk(0, 0, 0), atten = mk(1.f, 1.f, 1.f), toL = mk(0, 0, 0);
+            float ndl = 0.f, lmin = 0.f, lmax = 0.f;
+            bool front = false;
             uint64_t rngL = 0;
+            SphereRaw raw0;
+            raw0.p = mk(0, 0, 0); raw0.len = 1.f; raw0.sq = 0.f;
 
             enum { PC_RAY_RESULT, PC_SHADOW_RESULT, PC_LIGHT_SETUP, PC_LIGHT_ACCUM, PC_SHADE_END, PC_NEXT_RAY, PC_EXIT };
             int pc = PC_RAY_RESULT;
             if (stage == WS_SHADOW) {
-                const float4 sn = W.shN[a], sw = W.shWhere[a], f0 = W.shF0[a], f1 = W.shF1[a];
-                n = xyz(sn); hit_l1 = sn.w; where = xyz(sw); hit_l2 = sw.w;
-                face0 = xyz(f0); lmin = f0.w; face1 = xyz(f1); lmax = f1.w;
-                atten = xyz(W.shAtt[a]); toL = xyz(W.shToL[a]);
-                tex = xyz(W.shTex[a]); transp = xyz(W.shTransp[a]); refl = xyz(W.shRefl[a]); lum = xyz(W.shLum[a]);
-                rngL = W.rngL[a];
+                const float4 sp = W.shP[a], sf = W.shFace[a];
+                P = xyz(sp); ndl = sp.w; face = xyz(sf); front = (sf.w != 0.f);
+                if (attStored) atten = xyz(W.shAtt[a]);
+                // the request that was answered still holds the hit point and the direction to the light
+                const float4 qo = W.reqO[in][q], qd = W.reqD[in][q];
+                where = xyz(qo); lmin = qo.w; toL = xyz(qd); lmax = qd.w;
+                if (multiLight) { n = xyz(W.shN[a]); rngL = W.rngL[a]; }
                 pc = PC_SHADOW_RESULT;
+            } else {
+                const float4 c0 = ringA[head * 3 + 0], c1 = ringA[head * 3 + 1], c2 = ringA[head * 3 + 2];
+                cur_o = xyz(c0); cur_tmin = c0.w; cur_d = xyz(c1); cur_excl = __float_as_uint(c1.w); cur_w = xyz(c2);
+                cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
+                cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
             }
-            bool finished = false, freshShading = false, curDirty = false;
+            bool finished = false, shadedNow = false, rngDirty = false, outDirty = false;
             uint32_t emitStage = WS_RAY;
 
             while (pc != PC_EXIT) {
                 if (pc == PC_RAY_RESULT) {
                     if (res_tri == RT_NONE) { pc = PC_NEXT_RAY; continue; }
                     // SHADE_BEGIN (:532-561)
-                    hit_tri = res_tri; hit_t = res_t; hit_l1 = res_l1; hit_l2 = res_l2;
+                    hit_tri = res_tri;
+                    const float hit_t = res_t, hit_l1 = res_l1, hit_l2 = res_l2;
                     const float *shade = S.triShade + 24 * (size_t)hit_tri;
                     const int m = __float_as_int(shade[21]);
                     const float *uv = shade + 15;
                     where = along(cur_o, hit_t, cur_d);
                     n = shading_normal<false>(S, sh, where, cur_o, cur_d, hit_tri, hit_l1, hit_l2, shade, m, cn);
-                    tex = mk(0, 0, 0); transp = mk(0, 0, 0); refl = mk(0, 0, 0); lum = mk(0, 0, 0);
-                    face0 = mk(0.1f, 0.1f, 0.1f); face1 = mk(0.1f, 0.1f, 0.1f);
+                    V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
                     if (0 <= m) {
                         const int mc = CH_COUNT * m;
                         uint32_t raw, w;
@@ -292,24 +295,38 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         w = S.matSize[2 * (mc + CH_LUMINANCE)];
                         if (0 < w) lum = texel<false>(S, sh, S.matStart[mc + CH_LUMINANCE], w, S.matSize[2 * (mc + CH_LUMINANCE) + 1], uv, hit_l1, hit_l2, raw, cn);
                     }
-                    // The light loop (:563-637) will draw from here ...
+                    // :642-644 now (the light loop does not touch `out`), then the light-independent factors of :649-651
+                    out.x += (1.f - out.x) * lum.x * cur_w.x;
+                    out.y += (1.f - out.y) * lum.y * cur_w.y;
+                    out.z += (1.f - out.z) * lum.z * cur_w.z;
+                    outDirty = true;
+                    front = (dot3(n, cur_d) <= 0.f);
+                    P.x = (1.f - out.x) * cur_w.x * (1.f - transp.x) * tex.x;
+                    P.y = (1.f - out.y) * cur_w.y * (1.f - transp.y) * tex.y;
+                    P.z = (1.f - out.z) * cur_w.z * (1.f - transp.z) * tex.z;
+                    face = mk(0.1f, 0.1f, 0.1f); // :540
+                    // The light loop (:563-637) draws one GetSpherePoint per light of a sampled type (:573,:595).  Make those
+                    // draws now: keep light 0's, remember where light 1's start, and leave the generator behind them all.
                     rngL = rng;
-                    // ... and the main cursor skips those draws: one GetSpherePoint per light of a sampled type (:573,:595)
                     for (uint32_t k = 0; k < S.lightCount; ++k) {
                         const int type = S.lightType[k];
-                        if ((type >= 1 && type <= 9)) (void)sphere_point(rng, 1.f);
+                        if (type >= 1 && type <= 9) {
+                            const SphereRaw rr = sphere_raw(rng);
+                            if (k == 0) raw0 = rr;
+                        }
+                        if (k == 0) rngL = rng;
                     }
+                    rngDirty = true;
                     // the hit's spawns (:656-722), ahead of its light loop: nothing below depends on the face lights
                     if (cur_bounces > 0) {
-                        const int front = (dot3(n, cur_d) <= 0.f) ? 1 : 0;
+                        const int frontI = front ? 1 : 0;
                         const float total_rt = RT_MAX2(RT_MAX2(refl.x + transp.x, refl.y + transp.y), refl.z + transp.z);
                         const float dif = (total_rt < 1.f) ? 1.f - total_rt : 0.f;
-                        float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
                         bool open = true;
                         V3 w = mk(cur_w.x * tex.x * dif, cur_w.y * tex.y * dif, cur_w.z * tex.z * dif);
                         if (3.f / 256.f <= w.x + w.y + w.z) { // diffuse bounce (:664-683)
-                            V3 nd = sphere_point(rng, 1.f);
-                            if (front != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
+                            V3 nd = sphere_scaled(sphere_raw(rng), 1.f);
+                            if (frontI != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
                             ringA[tail * 3 + 0] = pack4(where, 0.f);
                             ringA[tail * 3 + 1] = pack4(nd, __uint_as_float(hit_tri));
                             ringA[tail * 3 + 2] = pack4(w, __uint_as_float(0u));
@@ -339,30 +356,35 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         }
                     }
                     j = 0;
-                    freshShading = true;
+                    shadedNow = true;
                     pc = PC_LIGHT_SETUP;
                 } else if (pc == PC_LIGHT_SETUP) { // :563-607
                     if (j >= S.lightCount) { pc = PC_SHADE_END; continue; }
-                    toL = mk(0.f, 0.f, 0.f); atten = mk(1.f, 1.f, 1.f);
+                    toL = mk(0.f, 0.f, 0.f); atten = mk(1.f, 1.f, 1.f); attStored = false;
                     lmin = 0.f; lmax = 0.f;
                     const int type = S.lightType[j];
-                    if (type == 1 || type == 2 || type == 7 || type == 8 || type == 9) {
-                        const V3 r = sphere_point(rngL, S.lightRadius[j]);
-                        const float *lp = S.lightPos + 4 * j;
-                        toL.x = r.x + lp[0] - where.x;
-                        toL.y = r.y + lp[1] - where.y;
-                        toL.z = r.z + lp[2] - where.z;
-                        lmax = sqrt_rn(dot3(toL, toL));
-                        const float inv = 1.f / lmax;
-                        toL.x *= inv; toL.y *= inv; toL.z *= inv;
-                    } else if (type >= 3 && type <= 6) {
-                        const float *ld = S.lightDir + 4 * j;
-                        toL = sphere_point(rngL, S.lightSpread[j]);
-                        toL.x -= ld[0]; toL.y -= ld[1]; toL.z -= ld[2];
-                        const float inv = 1.f / sqrt_rn(dot3(toL, toL));
-                        toL.x *= inv; toL.y *= inv; toL.z *= inv;
-                        lmax = RT_INF;
+                    if (type >= 1 && type <= 9) {
+                        // light 0 is only ever set up in the invocation that shaded the hit, where its draws are at hand
+                        const SphereRaw rr = (j == 0u) ? raw0 : sphere_raw(rngL);
+                        if (type >= 3 && type <= 6) {
+                            const float *ld = S.lightDir + 4 * j;
+                            toL = sphere_scaled(rr, S.lightSpread[j]);
+                            toL.x -= ld[0]; toL.y -= ld[1]; toL.z -= ld[2];
+                            const float inv = 1.f / sqrt_rn(dot3(toL, toL));
+                            toL.x *= inv; toL.y *= inv; toL.z *= inv;
+                            lmax = RT_INF;
+                        } else {
+                            const V3 rp = sphere_scaled(rr, S.lightRadius[j]);
+                            const float *lp = S.lightPos + 4 * j;
+                            toL.x = rp.x + lp[0] - where.x;
+                            toL.y = rp.y + lp[1] - where.y;
+                            toL.z = rp.z + lp[2] - where.z;
+                            lmax = sqrt_rn(dot3(toL, toL));
+                            const float inv = 1.f / lmax;
+                            toL.x *= inv; toL.y *= inv; toL.z *= inv;
+                        }
                     }
+                    ndl = dot3(n, toL);
                     if (lmin < lmax) { // shadow ray (:608-611): leave the machine until the grid has answered
                         emit = true; emitStage = WS_SHADOW; ro = where; rd = toL; rtmin = lmin; rtmax = lmax; rexcl = hit_tri;
                         pc = PC_EXIT;
@@ -379,6 +401,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                             if (0 < w) tr = texel<false>(S, sh, S.matStart[CH_COUNT * om + CH_TRANSPARENCY], w, S.matSize[2 * (CH_COUNT * om + CH_TRANSPARENCY) + 1], oshade + 15, res_l1, res_l2, raw, cn);
                         }
                         atten.x *= tr.x; atten.y *= tr.y; atten.z *= tr.z;
+                        attStored = true;
                         if (0.f < atten.x && 0.f < atten.y && 0.f < atten.z) {
                             lmin = res_t;
                             emit = true; emitStage = WS_SHADOW; ro = where; rd = toL; rtmin = lmin; rtmax = lmax; rexcl = hit_tri;
@@ -386,44 +409,31 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         }
                     }
                 } else if (pc == PC_LIGHT_ACCUM) { // :628-636
-                    const float ndl = dot3(n, toL);
                     const float mag = __builtin_fabsf(ndl);
                     const float x = lmax / S.lightHalfAtt[j];
-                    const float fall = __double2float_rn(exp2(-(double)x));
+                    const float fall = (x == 0.f) ? 1.f : __double2float_rn(exp2(-(double)x)); // exp2(-0) is exactly 1
                     const float e = mag * (fall == fall ? fall : 1.f);
                     const float *lc = S.lightCol + 4 * j;
-                    if (0.f <= ndl) {
-                        face1.x += (1.f - face1.x) * atten.x * e * lc[0];
-                        face1.y += (1.f - face1.y) * atten.y * e * lc[1];
-                        face1.z += (1.f - face1.z) * atten.z * e * lc[2];
-                    } else {
-                        face0.x += (1.f - face0.x) * atten.x * e * lc[0];
-                        face0.y += (1.f - face0.y) * atten.y * e * lc[1];
-                        face0.z += (1.f - face0.z) * atten.z * e * lc[2];
+                    if ((0.f <= ndl) == front) { // face[1] collects the lights in front of the normal, face[0] the others (:632-635)
+                        face.x += (1.f - face.x) * atten.x * e * lc[0];
+                        face.y += (1.f - face.y) * atten.y * e * lc[1];
+                        face.z += (1.f - face.z) * atten.z * e * lc[2];
                     }
                     ++j;
                     pc = PC_LIGHT_SETUP;
-                } else if (pc == PC_SHADE_END) { // :639-653 (the spawns of :656-722 were made when the hit was shaded)
-                    out.x += (1.f - out.x) * lum.x * cur_w.x;
-                    out.y += (1.f - out.y) * lum.y * cur_w.y;
-                    out.z += (1.f - out.z) * lum.z * cur_w.z;
-                    const int front = (dot3(n, cur_d) <= 0.f) ? 1 : 0;
-                    const V3 lit = front ? face1 : face0;
-                    out.x += (1.f - out.x) * cur_w.x * (1.f - transp.x) * tex.x * lit.x;
-                    out.y += (1.f - out.y) * cur_w.y * (1.f - transp.y) * tex.y * lit.y;
-                    out.z += (1.f - out.z) * cur_w.z * (1.f - transp.z) * tex.z * lit.z;
+                } else if (pc == PC_SHADE_END) { // :647-651
+                    out.x += P.x * face.x;
+                    out.y += P.y * face.y;
+                    out.z += P.z * face.z;
+                    outDirty = true;
                     pc = PC_NEXT_RAY;
                 } else { // PC_NEXT_RAY (:509)
                     head = (head + 1) % RT_RING;
                     if (head == tail) { finished = true; pc = PC_EXIT; continue; }
-                    const float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
-                    c0 = ringA[head * 3 + 0]; c1 = ringA[head * 3 + 1]; c2 = ringA[head * 3 + 2];
-                    cur_o = xyz(c0); cur_d = xyz(c1); cur_w = xyz(c2);
-                    cur_tmin = c0.w;
-                    cur_excl = __float_as_uint(c1.w);
+                    const float4 c0 = ringA[head * 3 + 0], c1 = ringA[head * 3 + 1], c2 = ringA[head * 3 + 2];
+                    cur_o = xyz(c0); cur_tmin = c0.w; cur_d = xyz(c1); cur_excl = __float_as_uint(c1.w); cur_w = xyz(c2);
                     cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
                     cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
-                    curDirty = true;
                     if (cur_fromCamera) {
                         res_tri = camera_scan(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         pc = PC_RAY_RESULT;
@@ -442,7 +452,6 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             if (!finished && laState == 0u && W.lookAhead) {
                 const int nx = (head + 1) % RT_RING;
                 if (nx != tail) {
-                    const float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
                     const float4 n0 = ringA[nx * 3 + 0], n1 = ringA[nx * 3 + 1], n2 = ringA[nx * 3 + 2];
                     if ((__float_as_uint(n2.w) & 1u) == 0u) { // a grid ray (camera-type rays are answered inline)
                         emitLa = true; lo3 = xyz(n0); latmin = n0.w; ld3v = xyz(n1); laexcl = __float_as_uint(n1.w);
@@ -455,58 +464,35 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 W.sampleOut[meta.x] = pack4(out, 0.f);
             } else {
                 // park the path in HBM until the grid has answered
-                W.rng[a] = rng;
-                W.outc[a] = pack4(out, hit_t);
-                W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | (laState << 10) |
-                                                       ((uint32_t)laIndex << 12) | (j << 16), hit_tri);
-                if (laState == 2u) W.laRes[a] = laAns;
-                if (curDirty) { // the ray in flight changed (popped from the ring) since the path was loaded
-                    W.cur0[a] = pack4(cur_o, cur_tmin);
-                    W.cur1[a] = pack4(cur_d, __uint_as_float(cur_excl));
-                    W.cur2[a] = pack4(cur_w, __uint_as_float(((uint32_t)cur_bounces << 1) | (uint32_t)cur_fromCamera));
-                }
+                if (rngDirty) W.rng[a] = rng;
+                if (outDirty) W.outc[a] = pack4(out, 0.f);
+                W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | ((attStored ? 1u : 0u) << 9) |
+                                                       (laState << 10) | ((uint32_t)laIndex << 12) | (j << 16), hit_tri);
+                if (laState == 2u && laFetched) W.laRes[a] = laAns;
                 if (emitStage == WS_SHADOW) {
-                    W.rngL[a] = rngL;
-                    W.shF0[a] = pack4(face0, lmin);
-                    W.shF1[a] = pack4(face1, lmax);
-                    W.shAtt[a] = pack4(atten, 0.f);
-                    W.shToL[a] = pack4(toL, 0.f);
-                    if (freshShading) {
-                        W.shN[a] = pack4(n, hit_l1);
-                        W.shWhere[a] = pack4(where, hit_l2);
-                        W.shTex[a] = pack4(tex, 0.f);
-                        W.shTransp[a] = pack4(transp, 0.f);
-                        W.shRefl[a] = pack4(refl, 0.f);
-                        W.shLum[a] = pack4(lum, 0.f);
+                    W.shP[a] = pack4(P, ndl);
+                    W.shFace[a] = pack4(face, front ? 1.f : 0.f);
+                    if (attStored) W.shAtt[a] = pack4(atten, 0.f);
+                    if (multiLight) {
+                        W.rngL[a] = rngL;
+                        if (shadedNow) W.shN[a] = pack4(n, 0.f);
                     }
                 }
             }
         }
-        // every lane of the wave arrives here: one atomic per wave for the requests of the next round; a path's
-        // look-ahead request sits right behind its main request
-        const uint32_t mineN = (emit ? 1u : 0u) + (emitLa ? 1u : 0u);
-        uint32_t incl = mineN;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += up;
-        }
-        const uint32_t waveTotal = __shfl(incl, 63, 64);
-        uint32_t base = 0;
-        if (waveTotal) {
-            if (lane == 63) base = atomicAdd(&countOut[shard], waveTotal);
-            base = __shfl(base, 63, 64);
-        }
-        const uint32_t slot = shard * W.queueStride + base + incl - mineN;
+        // every lane of the wave arrives here: one atomic per wave and queue slice for the requests of the next round
+        const uint32_t slot = shard * W.shardCap + wave_append(&countOut[shard], emit);
+        const uint32_t slotLa = (RT_WF_SHARDS + shard) * W.shardCap + wave_append(&countOut[RT_WF_SHARDS + shard], emitLa);
         if (emit) {
             W.reqO[outq][slot] = pack4(ro, rtmin);
             W.reqD[outq][slot] = pack4(rd, rtmax);
             W.reqX[outq][slot] = make_uint2(rexcl, a);
         }
         if (emitLa) {
-            W.reqO[outq][slot + 1] = pack4(lo3, latmin);
-            W.reqD[outq][slot + 1] = pack4(ld3v, RT_INF);
-            W.reqX[outq][slot + 1] = make_uint2(laexcl, a | 0x80000000u);
+            W.reqO[outq][slotLa] = pack4(lo3, latmin);
+            W.reqD[outq][slotLa] = pack4(ld3v, RT_INF);
+            W.reqX[outq][slotLa] = make_uint2(laexcl, a);
+            W.laSlot[a] = slotLa;
         }
     }
 }
@@ -524,17 +510,17 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
-    const uint32_t blocksPerShard = W.queueStride >> 8;
+    const uint32_t blocksPerShard = W.shardCap >> 8; // grid: RT_WF_QSHARDS queue slices x workgroups per slice
     const uint32_t shard = blockIdx.x / blocksPerShard;
     const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
-    const uint32_t total = W.counts[(round % 3) * RT_WF_SHARDS + shard];
+    const uint32_t total = W.counts[(round % 3) * RT_WF_QSHARDS + shard];
     if (local0 >= total) return; // whole workgroup beyond the slice's entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     if (threadIdx.x < RT_WF_SORT_BINS) binCount[threadIdx.x] = 0u;
     __syncthreads();
 
     const uint32_t in = round & 1;
-    const uint32_t mine = shard * W.queueStride + local0 + threadIdx.x;
+    const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;
     const bool active = local0 + threadIdx.x < total;
     const uint32_t copy = blockIdx.x % RT_WF_SORT_COPIES;
     const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
@@ -593,7 +579,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     }
     __syncthreads();
     if (active) {
-        uint4 *stagingOut = W.cont[0] + 4 * (size_t)mine;
+        uint4 *stagingOut = W.stageEnt + 4 * (size_t)mine;
         stagingOut[0] = make_uint4(mine, cell | ((bin | (copy << 6)) << 24), endCell, excluded);
         stagingOut[1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(tmin));
         stagingOut[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
@@ -604,10 +590,10 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
 __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round)
 {
     __shared__ uint32_t base[RT_WF_SORT_BINS * RT_WF_SORT_COPIES];
-    const uint32_t blocksPerShard = W.queueStride >> 8;
+    const uint32_t blocksPerShard = W.shardCap >> 8;
     const uint32_t shard = blockIdx.x / blocksPerShard;
     const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
-    const uint32_t total = W.counts[(round % 3) * RT_WF_SHARDS + shard];
+    const uint32_t total = W.counts[(round % 3) * RT_WF_QSHARDS + shard];
     if (local0 >= total && blockIdx.x != 0) return; // workgroup 0 always publishes the total
     if (threadIdx.x < RT_WF_SORT_BINS) { // one wave: exclusive prefix over (bin, copy), bin-major
         uint32_t h[RT_WF_SORT_COPIES], sum = 0;
@@ -626,372 +612,33 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
     }
     __syncthreads();
     if (local0 + threadIdx.x < total) {
-        const uint32_t mine = shard * W.queueStride + local0 + threadIdx.x;
-        const uint4 *stagingIn = W.cont[0] + 4 * (size_t)mine;
+        const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;
+        const uint4 *stagingIn = W.stageEnt + 4 * (size_t)mine;
         uint4 e0 = stagingIn[0], e1 = stagingIn[1], e2 = stagingIn[2], e3 = stagingIn[3];
         const uint32_t tag = e0.y >> 24; // bin | copy << 6
         const uint32_t at = base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + e3.w;
         e0.y &= 0xffffffu;
         e3.w = 0u;
-        uint4 *sortedOut = W.cont[1] + 4 * (size_t)at;
+        uint4 *sortedOut = W.sortedEnt + 4 * (size_t)at;
         sortedOut[0] = e0; sortedOut[1] = e1; sortedOut[2] = e2; sortedOut[3] = e3;
     }
 }
 
-// ---- stage 3: grid traversal in resumable passes -----------------------------------------------------------------------
-// One queued ray per lane (raytrace_opencl.c:324-401); one workgroup per 256 queue entries, no fetch atomics.
-//
-// WALK, THEN TEST.  Where a ray walks does not depend on what it hits -- only where it stops does: the reference resets
-// its running maximum in every cell (:366) and ends at the first cell that produced any hit (:380).  So a lane walks
-// freely (one cell per iteration: occupancy bit from the cached 4x4x4 block word, end-cell test, branch-free step of the
-// axis with the smallest plane distance, one IEEE divide) and only RECORDS the dense ids of the occupied cells it passes
-// in a small per-lane list in LDS.  When lists fill up, or too few lanes are still walking, the wave tests: every lane
-// goes through its recorded cells in path order (next cell's range load in flight while the current cell's contiguous
-// candidate records are tested); the first cell with a hit ends the ray, and a ray without a hit carries on walking from
-// where it stands.  Walking iterations carry no long-latency loads and no divergent scan code, which is what made the
-// interleaved version slow (5,700 cycles per iteration, 28 of 64 lanes busy: profiles/r01_*).
-//
-// A ray gets `budget` cell visits per pass.  Rays still walking when it runs out are appended to the continuation
-// queue (one atomic per workgroup, aggregated through LDS) and resumed by the next pass re-packed into full waves.
-// Results do not depend on where a walk is cut or tested: the continuation carries the exact DDA state.
-#ifndef RT_WF_TRACE_WAVES
-#define RT_WF_TRACE_WAVES 6
-#endif
-#ifndef RT_WF_LIST
-#define RT_WF_LIST 8              // occupied cells a lane may record before it has to test them (LDS: 4 B x 256 each)
-#endif
-#define RT_WF_SPIN_LIMIT 16384u
-#ifndef RT_WF_EPOCH
-#define RT_WF_EPOCH 1024          // cell visits between two in-workgroup compactions of the live rays.  A walk has at most
-                                  // 766 visits, so by default compaction never triggers: measured, re-packing (in the
-                                  // workgroup or by extra passes) costs more in flushes and barriers than it saves
-#endif
-#ifndef RT_WF_UNROLL
-#define RT_WF_UNROLL 4            // cell visits between two checks of the wave's walk/test decision
-#endif
-#ifndef RT_WF_STALL_WEIGHT
-#define RT_WF_STALL_WEIGHT 1      // test once (lanes stalled on a full list) x weight exceeds the lanes still walking
-#endif
-enum { TRACE_FRESH = 0, TRACE_CONT = 1, TRACE_SORTED = 2 }; // where a launch takes its rays from
-template <int MODE>
-__global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
-                                                                         const uint32_t pass, const uint32_t budgetPerRay)
-{
-    __shared__ float planes[3 * (RT_GRID_DIV + 1)];
-    // One LDS block with two lives: while a wave walks and tests it holds the per-lane cell lists and the per-wave
-    // test scratch; at an epoch boundary (lists empty) it is the staging area of the workgroup's ray compaction.
-    constexpr int kStageWords = 16; // q cell endCell excluded | dx dy dz tmin | tmax o.xyz | d.xyz budget
-    constexpr int kListWords = RT_WF_LIST * 256, kOwnerWords = 4 * RT_WF_LIST * 64 / 4, kKeyWords = 4 * 64 * 2;
-    constexpr int kScratchWords = (kStageWords * 256 > kListWords + kOwnerWords + kKeyWords) ? kStageWords * 256 : kListWords + kOwnerWords + kKeyWords;
-    __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchWords];
-    uint32_t (*cellList)[256] = reinterpret_cast<uint32_t (*)[256]>(scratch);                                  // [entry][thread]
-    uint8_t (*ownerOf)[RT_WF_LIST * 64] = reinterpret_cast<uint8_t (*)[RT_WF_LIST * 64]>(scratch + kListWords); // per wave: lane that recorded item c
-    unsigned long long (*keyOf)[64] = reinterpret_cast<unsigned long long (*)[64]>(scratch + kListWords + kOwnerWords); // per wave and lane
-    uint32_t (*stage)[256] = reinterpret_cast<uint32_t (*)[256]>(scratch);                                     // [word][slot]
-    __shared__ uint32_t spillWave[4], spillBase, liveWave[4];
-
-    constexpr bool FRESH = (MODE == TRACE_FRESH);
-    // one workgroup per 256 entries of one shard's slice, or (sorted input) of the whole sorted array
-    const uint32_t blocksPerShard = W.queueStride >> 8;
-    const uint32_t shard = (MODE == TRACE_SORTED) ? blockIdx.x % RT_WF_SHARDS : blockIdx.x / blocksPerShard;
-    const uint32_t local0 = (MODE == TRACE_SORTED) ? blockIdx.x * 256 : (blockIdx.x - shard * blocksPerShard) * 256;
-    // input: the round's fresh requests (pass 0), what the previous pass spilled, or the round's length-sorted entries
-    const uint32_t total = (MODE == TRACE_SORTED) ? W.sortTotal[0]
-                         : FRESH ? W.counts[(round % 3) * RT_WF_SHARDS + shard] : W.contCounts[(pass - 1) * RT_WF_SHARDS + shard];
-    if (local0 >= total) return; // whole workgroup beyond the entries
-    const uint32_t localIdx = local0 + threadIdx.x;
-    const uint32_t mine = (MODE == TRACE_SORTED) ? localIdx : shard * W.queueStride + localIdx;
-    for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
-    __syncthreads();
-
-    const uint32_t in = round & 1;
-    const uint4 *__restrict__ contIn = W.cont[(pass + 1) & 1];
-    uint4 *__restrict__ contOut = W.cont[pass & 1];
-    const GridBlock *__restrict__ gridBlock = reinterpret_cast<const GridBlock *>(S.gridBlock);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
-    const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
-
-    bool active = localIdx < total;
-    uint32_t q = 0, excluded = RT_NONE, wordAt = 0, wordRank = 0, wordLo = 0, wordHi = 0;
-    V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
-    float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    uint32_t cell = 0;             // cx | cy << 8 | cz << 16
-    uint32_t endCell = 0xffffffffu; // same packing; all ones = the ray has no end cell (tmax infinite)
-
-    if (active) {
-        if (FRESH) {
-            q = mine;
-            const float4 ro = W.reqO[in][q], rd = W.reqD[in][q];
-            o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
-            excluded = W.reqX[in][q].x;
-            // start / end cells (:351-362)
-            int cx = 0, cy = 0, cz = 0;
-            V3 from = along(o, tmin, d);
-            bind_in_cube(from, d, lo, hi);
-#pragma unroll
-            for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-                if (planes[cx + div] < from.x) cx += div;
-                if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
-                if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
-            }
-            cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
-            if (tmax < RT_INF) {
-                V3 to = along(o, tmax, d);
-                bind_in_cube(to, d, lo, hi);
-                int ex = 0, ey = 0, ez = 0;
-#pragma unroll
-                for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-                    if (planes[ex + div] < to.x) ex += div;
-                    if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
-                    if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
-                }
-                endCell = (uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16);
-            }
-            // distances from the ray ORIGIN to the next plane of each axis (:383-385)
-            dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
-            dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
-            dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
-        } else {
-            // a continuation entry is self-contained (64 B, read in queue order): no gather back into the request arrays
-            const uint4 c0 = contIn[4 * (size_t)mine], c1 = contIn[4 * (size_t)mine + 1];
-            const uint4 c2 = contIn[4 * (size_t)mine + 2], c3 = contIn[4 * (size_t)mine + 3];
-            q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
-            dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
-            o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
-            d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
-        }
-        wordAt = ((cell >> 2) & 63u) | ((cell >> 4) & 0xFC0u) | ((cell >> 6) & 0x3F000u);
-        const GridBlock gb = gridBlock[wordAt];
-        wordLo = gb.lo; wordHi = gb.hi; wordRank = gb.rank;
-    }
-
-    uint32_t budget = budgetPerRay;
-    uint32_t epochLeft = RT_WF_EPOCH; // cell visits left before the workgroup re-packs its rays
-    uint32_t spins = 0;               // walk-loop head iterations of this wave (guard against a logic error hanging the GPU)
-#ifdef RT_DIAG_STAMPS
-    unsigned long long dgWalk = 0, dgTest = 0, dgWalkIters = 0, dgBatches = 0, dgTestLanes = 0, dgCells = 0;
-    const unsigned long long dgStart = diag_stamp();
-#endif
-    uint32_t listed = 0;   // occupied cells recorded and not yet tested
-    bool walkEnded = false; // the walk itself is over (end cell reached or the grid left): only recorded cells can still hit
-
-#pragma unroll 1
-    for (;;) {
-        // ---- walk: no long-latency loads, no scan code ----------------------------------------------------------------
-#ifdef RT_DIAG_STAMPS
-        const unsigned long long dgW0 = diag_stamp();
-#endif
-#pragma unroll 1
-        for (;;) {
-#ifdef RT_DIAG_STAMPS
-            dgWalkIters++;
-#endif
-            const bool canWalk = active && !walkEnded && budget != 0 && epochLeft != 0 && listed < RT_WF_LIST;
-            const unsigned long long walkers = __ballot(canWalk);
-            // A test batch costs a chain of dependent gathers whatever the number of lanes in it, a walking iteration is
-            // cheap: walk until nobody can, or until the lanes stalled on a full list outnumber the walkers.
-            if (walkers == 0ull) break;
-            const int stalled = __popcll(__ballot(active && !walkEnded && budget != 0 && epochLeft != 0 && listed >= RT_WF_LIST));
-            if (stalled * RT_WF_STALL_WEIGHT > __popcll(walkers)) break;
-            if (++spins > RT_WF_SPIN_LIMIT) break; // cannot happen (a ray makes at most 766 visits); keeps a logic error from hanging the GPU
-#pragma unroll
-            for (int u = 0; u < RT_WF_UNROLL; ++u) { // the checks above are re-done every RT_WF_UNROLL cell visits
-                if (active && !walkEnded && budget != 0 && epochLeft != 0 && listed < RT_WF_LIST) {
-                    // occupancy bit of this cell in its 4x4x4 block word
-                    const uint32_t bit = (cell & 3u) | ((cell >> 6) & 12u) | ((cell >> 12) & 48u);
-                    const uint32_t half = (bit & 32u) ? wordHi : wordLo;
-                    if ((half >> (bit & 31u)) & 1u) {
-                        const uint32_t below = (bit & 32u) ? (uint32_t)__popc(wordLo) + (uint32_t)__popc(wordHi & ((1u << (bit & 31u)) - 1u))
-                                                           : (uint32_t)__popc(wordLo & ((1u << bit) - 1u));
-                        cellList[listed][threadIdx.x] = wordRank + below; // dense cell id
-                        ++listed;
-                    }
-                    --budget;
-                    --epochLeft;
-                    // the end cell ends the walk after it has been visited (:380-381)
-                    bool done = (cell == endCell);
-                    if (!done) {
-                        // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
-                        const bool sxm = (dx < dy) & (dx < dz);
-                        const bool sym = !sxm & (dy < dz);
-                        const float dd = sxm ? d.x : (sym ? d.y : d.z);
-                        const float oo = sxm ? o.x : (sym ? o.y : o.z);
-                        const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);
-                        const uint32_t c = (cell >> shift) & 255u;
-                        const bool pos = (0.f <= dd);
-                        done = pos ? (c == RT_GRID_DIV - 1) : (c == 0u); // the step would leave the grid (:389,:393,:397)
-                        if (!done) {
-                            const uint32_t axisBase = sxm ? 0u : (sym ? (uint32_t)(RT_GRID_DIV + 1) : (uint32_t)(2 * (RT_GRID_DIV + 1)));
-                            // plane index of the NEW cell: c+1+1 going up, c-1+0 going down
-                            const float nd = (planes[axisBase + (pos ? c + 2u : c - 1u)] - oo) / dd;
-                            cell = pos ? cell + (1u << shift) : cell - (1u << shift);
-                            dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
-                            const uint32_t at = ((cell >> 2) & 63u) | ((cell >> 4) & 0xFC0u) | ((cell >> 6) & 0x3F000u);
-                            if (at != wordAt) {
-                                wordAt = at;
-                                const GridBlock gb = gridBlock[at];
-                                wordLo = gb.lo; wordHi = gb.hi; wordRank = gb.rank;
-                            }
-                        }
-                    }
-                    walkEnded = done;
-                }
-            }
-        }
-
-#ifdef RT_DIAG_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long dgT0 = diag_stamp();
-        dgWalk += dgT0 - dgW0;
-        dgBatches++;
-        dgTestLanes += (unsigned long long)__popcll(__ballot(active && listed));
-#endif
-        // ---- test, wave-cooperative: the wave's recorded cells are flattened into items and every lane takes one cell
-        // per round, whoever recorded it (ray data comes from the owner lane by ds_bpermute).  A cell's candidates are
-        // tested with the reference's running maximum (:366-379); the owner's answer is the hit of its EARLIEST cell
-        // (:380), found with an LDS atomicMin on (cell order, pair index); the owner then re-evaluates that one pair,
-        // which reproduces t, l1, l2 bit for bit.
-        {
-            const uint32_t mineN = active ? listed : 0u;
-            uint32_t incl = mineN;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off, 64);
-                if ((int)lane >= off) incl += up;
-            }
-            const uint32_t myBase = incl - mineN;
-            const uint32_t items = __shfl(incl, 63, 64);
-#ifdef RT_DIAG_STAMPS
-            dgCells += items;
-#endif
-            if (items) { // wave-uniform
-                volatile uint8_t *owners = ownerOf[wave];
-                volatile unsigned long long *keys = keyOf[wave];
-                for (uint32_t j = 0; j < mineN; ++j) owners[myBase + j] = (uint8_t)lane;
-                keys[lane] = ~0ull;
-                __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
-                for (uint32_t c0 = 0; c0 < items; c0 += 64) {
-                    const uint32_t c = c0 + lane;
-                    const bool has = c < items;
-                    const uint32_t owner = has ? owners[c] : 0u;
-                    // the owner's ray (all lanes take part in the permutes)
-                    const uint32_t ownerBase = __shfl(myBase, owner, 64);
-                    const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
-                    const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
-                    const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64);
-                    const uint32_t pexcl = __shfl(excluded, owner, 64);
-                    if (has) {
-                        const uint32_t j = c - ownerBase;
-                        const uint2 range = S.cellRange[cellList[j][(wave << 6) + owner]];
-                        uint32_t bestPair = RT_NONE;
-                        float tbest = ptmax; // running maximum, reset per cell (:366)
-                        for (uint32_t i = range.x; i < range.y; ++i) {
-                            uint32_t tri;
-                            float t, l1, l2;
-                            if (pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)i, po, pd, ptmin, tbest, pexcl, tri, t, l1, l2)) {
-                                bestPair = i; tbest = t;
-                            }
-                        }
-                        if (bestPair != RT_NONE)
-                            atomicMin((unsigned long long *)&keys[owner], ((unsigned long long)j << 32) | (unsigned long long)bestPair);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (mineN) {
-                    const unsigned long long key = keys[lane];
-                    if (key != ~0ull) {
-                        uint32_t tri;
-                        float t, l1, l2;
-                        pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key, o, d, tmin, tmax, excluded, tri, t, l1, l2);
-                        W.res[q] = make_uint4(tri, __float_as_uint(t), __float_as_uint(l1), __float_as_uint(l2));
-                        active = false;
-                    }
-                }
-            }
-            listed = 0;
-        }
-#ifdef RT_DIAG_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dgTest += diag_stamp() - dgT0;
-#endif
-        if (active && walkEnded) { // walked to the end without a hit
-            W.res[q] = make_uint4(RT_NONE, __float_as_uint(tmax), 0u, 0u);
-            active = false;
-        }
-        // anything left to walk in this epoch?
-        if (spins <= RT_WF_SPIN_LIMIT && __ballot(active && budget != 0 && epochLeft != 0) != 0ull) continue;
-
-        // ---- epoch boundary: the workgroup compacts its live rays into the lowest lanes, so that waves run full or not
-        // at all (the unbounded pass used to do 70 % of all wave-steps at 30 % lane utilisation).  All lists are empty
-        // here -- every recorded cell has been tested -- so only the DDA state travels.  Budgets are multiples of the
-        // epoch: the rays of a launch run out of budget together, at a boundary, and then all leave through the
-        // continuation queue below.
-        const bool live = active && budget != 0;
-        const unsigned long long liveMask = __ballot(live);
-        if (lane == 0) liveWave[wave] = (spins > RT_WF_SPIN_LIMIT) ? 0x40000000u : (uint32_t)__popcll(liveMask);
-        __syncthreads();
-        const uint32_t liveTotal = liveWave[0] + liveWave[1] + liveWave[2] + liveWave[3];
-        if (liveTotal == 0 || liveTotal >= 0x40000000u) break; // workgroup-uniform: nothing left, or a wave tripped its spin guard
-        uint32_t slot = (uint32_t)__popcll(liveMask & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; ++w) slot += liveWave[w];
-        if (live) {
-            stage[0][slot] = q; stage[1][slot] = cell; stage[2][slot] = endCell; stage[3][slot] = excluded;
-            stage[4][slot] = __float_as_uint(dx); stage[5][slot] = __float_as_uint(dy); stage[6][slot] = __float_as_uint(dz);
-            stage[7][slot] = __float_as_uint(tmin); stage[8][slot] = __float_as_uint(tmax);
-            stage[9][slot] = __float_as_uint(o.x); stage[10][slot] = __float_as_uint(o.y); stage[11][slot] = __float_as_uint(o.z);
-            stage[12][slot] = __float_as_uint(d.x); stage[13][slot] = __float_as_uint(d.y); stage[14][slot] = __float_as_uint(d.z);
-            stage[15][slot] = budget;
-        }
-        __syncthreads();
-        active = threadIdx.x < liveTotal;
-        if (active) {
-            const uint32_t t = threadIdx.x;
-            q = stage[0][t]; cell = stage[1][t]; endCell = stage[2][t]; excluded = stage[3][t];
-            dx = __uint_as_float(stage[4][t]); dy = __uint_as_float(stage[5][t]); dz = __uint_as_float(stage[6][t]);
-            tmin = __uint_as_float(stage[7][t]); tmax = __uint_as_float(stage[8][t]);
-            o = mk(__uint_as_float(stage[9][t]), __uint_as_float(stage[10][t]), __uint_as_float(stage[11][t]));
-            d = mk(__uint_as_float(stage[12][t]), __uint_as_float(stage[13][t]), __uint_as_float(stage[14][t]));
-            budget = stage[15][t];
-            wordAt = ((cell >> 2) & 63u) | ((cell >> 4) & 0xFC0u) | ((cell >> 6) & 0x3F000u);
-            const GridBlock gb = gridBlock[wordAt];
-            wordLo = gb.lo; wordHi = gb.hi; wordRank = gb.rank;
-        }
-        walkEnded = false;
-        listed = 0;
-        epochLeft = RT_WF_EPOCH;
-        __syncthreads(); // the staging area becomes list storage again
-    }
-
-    // rays that are still walking leave through the continuation queue: one atomic per workgroup
-    const unsigned long long spillMask = __ballot(active);
-    if (lane == 0) spillWave[wave] = (uint32_t)__popcll(spillMask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t n = spillWave[0] + spillWave[1] + spillWave[2] + spillWave[3];
-        spillBase = shard * W.queueStride + (n ? atomicAdd(&W.contCounts[pass * RT_WF_SHARDS + shard], n) : 0u);
-    }
-    __syncthreads();
-    if (active) {
-        uint32_t at = spillBase + (uint32_t)__popcll(spillMask & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; ++w) at += spillWave[w];
-        contOut[4 * (size_t)at + 0] = make_uint4(q, cell, endCell, excluded);
-        contOut[4 * (size_t)at + 1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(tmin));
-        contOut[4 * (size_t)at + 2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-        contOut[4 * (size_t)at + 3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
-    }
-}
-
-// ---- stage 3, lean variant for length-sorted input ------------------------------------------------------------------------
-// Same walk-then-test scheme and the same arithmetic per ray as wf_trace_kernel, stripped to what sorted input needs: no
-// visit budgets, no continuation queue, no in-workgroup compaction (waves already hold rays of similar length), waves of a
-// workgroup never synchronise after the plane table is staged.  The walk is VALU-issue bound (a round's waves outnumber the
+// ---- stage 3: grid traversal (raytrace_opencl.c:324-401) ------------------------------------------------------------------
+// One sorted entry per lane.  WALK, THEN TEST: where a ray walks does not depend on what it hits -- only where it stops does:
+// the reference resets its running maximum in every cell (:366) and ends at the first cell that produced any hit (:380).  So a
+// lane walks freely and only RECORDS the occupied cells it passes in a small per-lane list in LDS; when lists fill up, or
+// nobody can walk any further, the wave tests the recorded cells cooperatively (the items of all lanes are flattened, a lane
+// takes one cell per round whoever recorded it, ray data comes from the owner lane by ds_bpermute); the first cell with a hit
+// ends the ray, a ray without a hit carries on walking from where it stands.  Results do not depend on where a walk is cut.
+// Waves of a workgroup never synchronise after the plane table is staged.  The walk is VALU-issue bound (a round's waves outnumber the
 // wave slots), so the step is built to cost as few vector instructions as possible:
 //   * per-ray constants of the step are precomputed per axis (signed cell increment, plane-table offset, exit coordinate);
 //   * the occupancy word of a 4x4x4 block is found at byte offset 3*(cell & 0xFCFCFC) of a sparsely indexed copy of the
-//     block table (two instructions instead of six), its bit with one multiply (bit-gather) and one bit-field extract;
+//     block table (two instructions instead of six: rt_device.h, gridBlockSparse), its bit with one multiply (bit-gather) and one bit-field extract;
 //   * an occupied cell is recorded as its packed coordinates only; the dense cell id (rank + popcount) is worked out in the
 //     test phase, where all 64 lanes have an item, instead of in the walk, where 6 of 64 lanes are on an occupied cell.
+#define RT_WF_SPIN_LIMIT 16384u
 #ifndef RT_WF_LEAN_WAVES
 #define RT_WF_LEAN_WAVES 4
 #endif
@@ -1004,7 +651,7 @@ __global__ __launch_bounds__(256, RT_WF_TRACE_WAVES) void wf_trace_kernel(const 
 #ifndef RT_WF_LEAN_STALL
 #define RT_WF_LEAN_STALL 64           // test once (lanes without room for another phase) x this exceeds the lanes still walking
 #endif
-__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_sorted_kernel(const RtDevScene S, const RtWavefront W)
+__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t cellList[RT_WF_LEAN_LIST][256];                 // [entry][thread] packed cells cx | cy<<8 | cz<<16
@@ -1024,7 +671,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_sorted_kernel(
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
     if (active) {
-        const uint4 *e = W.cont[1] + 4 * (size_t)mine;
+        const uint4 *e = W.sortedEnt + 4 * (size_t)mine;
         const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
         q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
         dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
@@ -1135,7 +782,9 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_sorted_kernel(
         dgWalk += dgT0 - dgW0;
         dgBatches++;
 #endif
-        // ---- test, wave-cooperative (see wf_trace_kernel): items = recorded cells of the whole wave, one per lane and round
+        // ---- test, wave-cooperative: items = recorded cells of the whole wave, one per lane and round.  A cell's candidates
+        // are tested with the reference's running maximum (:366-379); the owner's answer is the hit of its EARLIEST cell
+        // (:380), found with an LDS atomicMin on (cell order, pair index); the owner then re-evaluates that one pair.
         {
             const uint32_t mineN = listed;
             uint32_t incl = mineN;
@@ -1198,10 +847,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_sorted_kernel(
                 if (mineN) {
                     const unsigned long long key = keys[lane];
                     if (key != ~0ull) { // the owner re-evaluates the winning pair: t, l1, l2 bit for bit
-                        uint32_t tri;
+                        const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key;
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                         float t, l1, l2;
-                        pair_test(reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key, o, d, tmin, tmax, excluded, tri, t, l1, l2);
-                        W.res[q] = make_uint4(tri, __float_as_uint(t), __float_as_uint(l1), __float_as_uint(l2));
+                        pair_test_flat(r0, r1, r2, r3, o, d, tmin, tmax, excluded, t, l1, l2);
+                        W.res[q] = make_uint4(__float_as_uint(r0.w), __float_as_uint(t), __float_as_uint(l1), __float_as_uint(l2));
                         active = false;
                         walkEnded = true;
                     }
@@ -1269,21 +919,18 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t pass, uint32_t budget,
-                                       uint32_t blocks, hipStream_t stream)
-{
-    if (pass == 0 && wf->sortMode == 2) hipLaunchKernelGGL(wf_trace_sorted_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf);
-    else if (pass == 0 && wf->sortMode) hipLaunchKernelGGL(wf_trace_kernel<TRACE_SORTED>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
-    else if (pass == 0) hipLaunchKernelGGL(wf_trace_kernel<TRACE_FRESH>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
-    else hipLaunchKernelGGL(wf_trace_kernel<TRACE_CONT>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, pass, budget);
-    return hipGetLastError();
-}
-
-// setup + scatter of one round's requests (sorted trace input); same grid as the trace kernel
+// setup + scatter of one round's requests: one workgroup per 256 entries of every queue slice (surplus groups exit at once)
 extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
 {
     hipLaunchKernelGGL(wf_setup_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
     hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round);
+    return hipGetLastError();
+}
+
+// one workgroup per 256 sorted entries
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf);
     return hipGetLastError();
 }
 
