@@ -71,9 +71,21 @@ struct rtHipScene {
     size_t eventsUsed = 0;
     // wavefront pipeline (rt_wavefront.hip)
     int pipeline = RT_HIP_PIPELINE_WAVEFRONT;
-    RtWavefront wf{};
-    uint32_t samplesPerBatch = 1, logicBlocks = 1, traceBlocks = 1;
-    uint32_t *hostCount = nullptr; // pinned: queue length read back between round chunks
+    // The instance's tile slots are cut into contiguous GROUPS, each a view of `dev` (its own slice of tileIds, camStart/End,
+    // tileBuf) with its own path state and stream.  A frame runs the groups concurrently: while one group is in a phase that
+    // cannot fill the GPU (a round with few rays, a host read-back), the others' kernels do.  Per pixel nothing changes.
+    struct Group {
+        RtDevScene dev{};
+        RtWavefront wf{};
+        hipStream_t stream = nullptr;   // groups 1.. ; group 0 runs on the caller's stream
+        hipEvent_t done = nullptr;
+        uint32_t logicBlocks = 1, traceBlocks = 1, queueBlocks = 1;
+        uint32_t *hostCount = nullptr;  // pinned: queue length read back between round chunks
+        uint32_t rounds = 0;
+    };
+    std::vector<Group> groups;
+    hipEvent_t forkEvent = nullptr;
+    uint32_t samplesPerBatch = 1;
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum, sort]
     struct StageEvent { int stage; hipEvent_t a, b; };
     std::vector<StageEvent> stageEvents;
@@ -281,6 +293,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 HIP_OK(hipStreamSynchronize(sc->stream)); // `sparse` is freed at the end of this scope
             }
             if (sc->upload(range.data(), range.size(), &D.cellRange, "cellRange")) return -1;
+            D.cellCount = (uint32_t)range.size();
             uint32_t *dPairTri = nullptr;
             HIP_OK(hipMalloc((void **)&dPairTri, (size_t)(listSize ? listSize : 1) * 4));
             if (listSize) HIP_OK(hipMemcpyAsync(dPairTri, pairTri.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
@@ -361,60 +374,87 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         if (d->lightCount >= 65536u) return fail("lightCount %u too large", d->lightCount);
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, sc->device));
+        const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
         // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
         // result, staging + sorted entry
-        const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 16 + 4 + 2 * (2 * 40 + 16 + 2 * 64) + 16;
+        const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + 6 * (2 * 64 + 4) + 16;
         uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
         if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
         if (sb > d->sampleCount) sb = d->sampleCount;
         sc->samplesPerBatch = (uint32_t)sb;
-        // queue slices: the primary kernel's workgroups are dealt to the shards round-robin, 256 paths each at most
-        const uint64_t primaryBlocks = (uint64_t)nt * 64 * sb;
-        const uint64_t shardCap = ((primaryBlocks + RT_WF_SHARDS - 1) / RT_WF_SHARDS) * 256;
-        const uint64_t cap = shardCap * RT_WF_SHARDS;
-        if (cap > 0x7ffffff0ull) return fail("tile set too large for one batch");
-        RtWavefront &Wf = sc->wf;
-        Wf.capacity = (uint32_t)cap;
-        Wf.shardCap = (uint32_t)shardCap;
-        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
+        uint32_t groupCount = 1; // RT_WF_GROUPS: concurrent tile groups per instance (measured: no gain once rays are cut into segments)
+        if (const char *b = getenv("RT_WF_GROUPS")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) groupCount = (uint32_t)v; }
+        if (groupCount > nt) groupCount = nt ? (uint32_t)nt : 1u;
+        uint32_t lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
+        if (const char *b = getenv("RT_WF_LOOKAHEAD")) lookAhead = (b[0] != '0') ? 1u : 0u;
         const bool multiLight = d->lightCount > 1;
-        Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
-        if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
-            sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
-            sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
-            sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<uint4>(cap, &Wf.laRes) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
-            sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
-            sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
-            sc->alloc<uint4>(qcap, &Wf.res) || sc->alloc<float4>(pix * sb, &Wf.sampleOut) ||
-            sc->alloc<uint4>(qcap * 4, &Wf.stageEnt) || sc->alloc<uint4>(qcap * 4, &Wf.sortedEnt) ||
-            sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
-            sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(1, &Wf.sortTotal))
-            return -1;
-        HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
-        Wf.lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
-        if (const char *b = getenv("RT_WF_LOOKAHEAD")) Wf.lookAhead = (b[0] != '0') ? 1u : 0u;
-        HIP_OK(hipHostMalloc((void **)&sc->hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
-        const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        sc->traceBlocks = (uint32_t)(qcap / 256);  // one workgroup per 256 entries of every queue slice; surplus groups exit at once
-        sc->logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
-        if (sc->logicBlocks == 0) sc->logicBlocks = 1;
+        HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
+        sc->groups.resize(groupCount);
+        for (uint32_t g = 0; g < groupCount; ++g) {
+            rtHipScene::Group &G = sc->groups[g];
+            const uint32_t slot0 = (uint32_t)((uint64_t)nt * g / groupCount), slot1 = (uint32_t)((uint64_t)nt * (g + 1) / groupCount);
+            G.dev = D; // a view: same scene, a contiguous range of this instance's tile slots
+            G.dev.tileIds = D.tileIds + slot0;
+            G.dev.tileCount = slot1 - slot0;
+            G.dev.camStart = D.camStart + (size_t)slot0 * RT_TILE_PIXELS;
+            G.dev.camEnd = D.camEnd + (size_t)slot0 * RT_TILE_PIXELS;
+            G.dev.tileBuf = D.tileBuf + (size_t)slot0 * 3 * RT_TILE_PIXELS;
+            if (g > 0) HIP_OK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+            // queue slices: the primary kernel's workgroups are dealt to the shards round-robin, 256 paths each at most
+            const uint64_t gpix = (uint64_t)G.dev.tileCount * RT_TILE_PIXELS;
+            const uint64_t primaryBlocks = (uint64_t)G.dev.tileCount * 64 * sb;
+            const uint64_t shardCap = ((primaryBlocks + RT_WF_SHARDS - 1) / RT_WF_SHARDS) * 256;
+            const uint64_t cap = shardCap * RT_WF_SHARDS;
+            if (cap > 0x7ffffff0ull) return fail("tile set too large for one batch");
+            RtWavefront &Wf = G.wf;
+            Wf.capacity = (uint32_t)cap;
+            Wf.shardCap = (uint32_t)shardCap;
+            Wf.lookAhead = lookAhead;
+            const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
+            const uint64_t extraCap = qcap; // room for the extra segments of long rays (a round that would need more cuts fewer rays)
+            const uint64_t ecap = qcap + extraCap;
+            if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
+            Wf.extraCap = (uint32_t)extraCap;
+            Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
+            if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
+                sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
+                sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
+                sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<unsigned long long>(cap, &Wf.laKey) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
+                sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
+                sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
+                sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
+                sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) ||
+                sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
+                sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
+                sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(1, &Wf.sortTotal))
+                return -1;
+            HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
+            HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
+            HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
+            G.queueBlocks = (uint32_t)(qcap / 256);  // one workgroup per 256 entries of every queue slice; surplus groups exit at once
+            G.traceBlocks = (uint32_t)(ecap / 256);  // one workgroup per 256 sorted entries
+            G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
+            if (G.logicBlocks == 0) G.logicBlocks = 1;
+        }
+        HIP_OK(hipStreamSynchronize(sc->stream));
         const char *env = getenv("RT_HIP_PIPELINE");
         if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     }
     return 0;
 }
 
-// One frame through the staged pipeline: per sample batch -- primary, then rounds of (logic, trace) until no path is
-// waiting for the grid, then the ordered accumulate.  The round count is data dependent, so the queue length is read
-// back after every chunk of rounds (one small pinned copy + stream sync per chunk).
+// One frame through the staged pipeline: per sample batch and tile group -- primary, then rounds of (sort, trace, logic)
+// until no path is waiting for the grid, then the ordered accumulate.  The round count is data dependent, so the queue
+// length is read back after every chunk of rounds (one small pinned copy + stream sync per chunk and group).  Groups run
+// concurrently on their own streams, forked from and joined to `st`; with stage timing on they run one after the other on
+// `st`, so that a kernel's measured duration is its own.
 int render_wavefront(rtHipScene *sc, hipStream_t st)
 {
-    const RtDevScene &D = sc->dev;
-    RtWavefront &Wf = sc->wf;
-    auto stage = [&](int which, auto &&launch) -> hipError_t {
+    auto stage = [&](int which, hipStream_t on, auto &&launch) -> hipError_t {
         if (!sc->stageTiming) return launch();
         if (sc->stageEventsUsed == sc->stageEvents.size()) {
             rtHipScene::StageEvent e{};
@@ -426,42 +466,67 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
         }
         rtHipScene::StageEvent &e = sc->stageEvents[sc->stageEventsUsed++];
         e.stage = which;
-        hipError_t er = hipEventRecord(e.a, st);
+        hipError_t er = hipEventRecord(e.a, on);
         if (er != hipSuccess) return er;
         er = launch();
         if (er != hipSuccess) return er;
-        return hipEventRecord(e.b, st);
+        return hipEventRecord(e.b, on);
+    };
+    const bool serial = sc->stageTiming || sc->groups.size() == 1;
+    auto streamOf = [&](size_t g) { return (serial || g == 0) ? st : sc->groups[g].stream; };
+    if (!serial) {
+        HIP_OK(hipEventRecord(sc->forkEvent, st));
+        for (size_t g = 1; g < sc->groups.size(); ++g) HIP_OK(hipStreamWaitEvent(sc->groups[g].stream, sc->forkEvent, 0));
+    }
+    // Rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds (shade
+    // the primary hits | consume shadow + bounce answers, shade the bounce hits | consume their shadow answers) with a trace
+    // before the last two, so a chunk is 3 rounds.
+    auto issue_chunk = [&](rtHipScene::Group &G, hipStream_t on) -> int {
+        const uint32_t chunk = 3;
+        for (uint32_t k = 0; k < chunk && G.rounds < RT_WF_MAX_ROUNDS; ++k, ++G.rounds) {
+            const uint32_t r = G.rounds;
+            if (r > 0) { // the requests appended by logic(r-1): sort by predicted walk length, then walk the grid
+                HIP_OK(stage(4, on, [&] { return rtw_launch_sort(&G.dev, &G.wf, r, G.queueBlocks, on); }));
+                HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, G.traceBlocks, on); }));
+            }
+            HIP_OK(stage(1, on, [&] { return rtw_launch_logic(&G.dev, &G.wf, r, G.logicBlocks, on); }));
+        }
+        HIP_OK(hipMemcpyAsync(G.hostCount, G.wf.counts + (G.rounds % 3) * RT_WF_QSHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, on)); // main slices
+        return 0;
     };
     uint64_t rounds = 0;
-    for (uint32_t base = 0; base < D.sampleCount; base += sc->samplesPerBatch) {
-        Wf.sampleBase = base;
-        Wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, D.sampleCount - base);
-        HIP_OK(hipMemsetAsync(Wf.counts, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_QSHARDS, st));
-        HIP_OK(stage(0, [&] { return rtw_launch_primary(&D, &Wf, st); }));
-        uint32_t r = 0;
-        for (;;) {
-            // Rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds
-            // (shade the primary hits | consume shadow + bounce answers, shade the bounce hits | consume their shadow
-            // answers) with a trace after the first two, so the first chunk is 3 rounds; the trace after a chunk's last
-            // logic round is only issued once the host has seen that rays are waiting.
-            const uint32_t chunk = 3;
-            for (uint32_t k = 0; k < chunk && r < RT_WF_MAX_ROUNDS; ++k, ++r) {
-                if (r > 0) { // the requests appended by logic(r-1): sort by predicted walk length, then walk the grid
-                    HIP_OK(stage(4, [&] { return rtw_launch_sort(&D, &Wf, r, sc->traceBlocks, st); }));
-                    HIP_OK(stage(2, [&] { return rtw_launch_trace(&D, &Wf, sc->traceBlocks, st); }));
-                }
-                HIP_OK(stage(1, [&] { return rtw_launch_logic(&D, &Wf, r, sc->logicBlocks, st); }));
-            }
-            HIP_OK(hipMemcpyAsync(sc->hostCount, Wf.counts + (r % 3) * RT_WF_QSHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, st)); // main slices
-            HIP_OK(hipStreamSynchronize(st));
-            uint64_t waiting = 0;
-            for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += sc->hostCount[i];
-            if (waiting == 0) break;
-            if (r >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
+    const uint32_t sampleCount = sc->dev.sampleCount;
+    for (uint32_t base = 0; base < sampleCount; base += sc->samplesPerBatch) {
+        for (size_t g = 0; g < sc->groups.size(); ++g) {
+            rtHipScene::Group &G = sc->groups[g];
+            const hipStream_t on = streamOf(g);
+            G.wf.sampleBase = base;
+            G.wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, sampleCount - base);
+            G.rounds = 0;
+            HIP_OK(hipMemsetAsync(G.wf.counts, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_QSHARDS, on));
+            HIP_OK(stage(0, on, [&] { return rtw_launch_primary(&G.dev, &G.wf, on); }));
+            if (issue_chunk(G, on) != 0) return -1;
         }
-        rounds += r;
-        HIP_OK(stage(3, [&] { return rtw_launch_accum(&D, &Wf, base == 0 ? 1 : 0, st); }));
+        for (size_t g = 0; g < sc->groups.size(); ++g) {
+            rtHipScene::Group &G = sc->groups[g];
+            const hipStream_t on = streamOf(g);
+            for (;;) {
+                HIP_OK(hipStreamSynchronize(on));
+                uint64_t waiting = 0;
+                for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += G.hostCount[i];
+                if (waiting == 0) break;
+                if (G.rounds >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
+                if (issue_chunk(G, on) != 0) return -1;
+            }
+            rounds = std::max<uint64_t>(rounds, G.rounds);
+            HIP_OK(stage(3, on, [&] { return rtw_launch_accum(&G.dev, &G.wf, base == 0 ? 1 : 0, on); }));
+        }
     }
+    if (!serial)
+        for (size_t g = 1; g < sc->groups.size(); ++g) {
+            HIP_OK(hipEventRecord(sc->groups[g].done, sc->groups[g].stream));
+            HIP_OK(hipStreamWaitEvent(st, sc->groups[g].done, 0));
+        }
     sc->roundsLast = rounds;
     return 0;
 }
@@ -503,7 +568,12 @@ void rtHipSceneDestroy(rtHipScene *sc)
     if (sc->stream) (void)hipStreamSynchronize(sc->stream);
     for (auto &e : sc->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : sc->stageEvents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (sc->hostCount) (void)hipHostFree(sc->hostCount);
+    for (auto &G : sc->groups) {
+        if (G.hostCount) (void)hipHostFree(G.hostCount);
+        if (G.stream) { (void)hipStreamSynchronize(G.stream); (void)hipStreamDestroy(G.stream); }
+        if (G.done) (void)hipEventDestroy(G.done);
+    }
+    if (sc->forkEvent) (void)hipEventDestroy(sc->forkEvent);
     for (void *p : sc->allocs) (void)hipFree(p);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;

@@ -58,6 +58,7 @@ struct RtDevScene {
     // space, the same 3 MiB of touched lines
     const uint32_t *gridBlockSparse;
     const uint2 *cellRange;
+    uint32_t cellCount; // non-empty cells = entries of cellRange
     const float *pairRec;
     // materials
     uint32_t materialCount, texelCount;
@@ -86,7 +87,7 @@ struct RtDevScene {
 #define RT_WF_MAX_ROUNDS 100000
 #define RT_WF_SHARDS 256      // paths are born into one of this many shards (primary workgroup % RT_WF_SHARDS)
 #define RT_WF_QSHARDS (2 * RT_WF_SHARDS) // queue slices: [0,SHARDS) main requests (one per waiting path), [SHARDS,2*SHARDS) look-ahead requests
-#define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input: bin = (767 - predicted visits) / 12, 0 = longest
+#define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input (wf_setup_kernel), 0 = longest
 #define RT_WF_SORT_COPIES 4   // independent histograms (workgroup % copies) to spread the atomics
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
@@ -98,7 +99,7 @@ struct RtWavefront {
     unsigned long long *rngL; // lightCount > 1 only: where the current hit's NEXT light set-up draws from
     uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel  w: hit triangle
                              // z: head | tail<<4 | stage<<8 | attenuation stored<<9 | look-ahead state<<10 | look-ahead ring index<<12 | light<<16
-    uint4 *laRes;            // answer of the path's look-ahead ray while it waits to be consumed
+    unsigned long long *laKey; // answer (hitKey) of the path's look-ahead ray while it waits to be consumed
     uint32_t *laSlot;        // queue index of the look-ahead request issued last round
     float4 *outc;            // accumulated colour xyz
     float4 *ring;            // [capacity][12][3] the pixel's ray queue (:459-468): o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera;
@@ -113,15 +114,21 @@ struct RtWavefront {
     // single address sustains only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shard.
     float4 *reqO[2], *reqD[2]; // o.xyz,tmin | d.xyz,tmax
     uint2 *reqX[2];            // excluded triangle, path id
-    uint4 *res;                // hit triangle (0xffffffff = none), t, l1, l2 (float bits)
+    uint4 *res;                // round 0 only: the primary hit of the path -- triangle, t, l1, l2 (float bits)
+    unsigned long long *hitKey; // per request: segment << 32 | pair index of the hit in the lowest segment that has one; all ones = no hit
     uint32_t shardCap;         // entries per queue slice = paths per shard (multiple of 256)
     uint32_t *counts;          // [3][RT_WF_QSHARDS] queue lengths; round r reads [r%3], appends to [(r+1)%3]; zeroed in-stream by the logic kernel
     // Length-sorted trace input (wf_setup_kernel / wf_scatter_kernel): a round's requests become self-contained 64-byte entries
     // {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz,-} (DDA start state computed once), keyed by the PREDICTED
     // number of cell visits (exact for rays that hit nothing) and counting-sorted longest first, so that a wave holds rays of
     // similar length and the longest walks of the round start first.
-    uint4 *stageEnt;           // [2*capacity][4] entries in queue order, tagged with (bin, copy, rank)
-    uint4 *sortedEnt;          // [2*capacity][4] entries in sorted order
+    // A long ray becomes several entries (SEGMENTS, rt_wavefront.hip): segment 0 sits at its request's queue index (region A,
+    // [0, 2*capacity)), further segments are packed into region B ([2*capacity, 2*capacity + extraCap)).
+    uint4 *stageEnt;           // [2*capacity + extraCap][4] entries, {.., cell | (bin | copy<<6)<<24, ..} .. {.., rank in workgroup | segment<<24}
+    uint4 *sortedEnt;          // [2*capacity + extraCap][4] entries in sorted order, {d.xyz, segment}
+    uint32_t *sortRank;        // [2*capacity + extraCap] rank of the entry inside its (bin, copy) class
+    uint32_t *sortExtra;       // [1] entries in region B this round
+    uint32_t extraCap;         // capacity of region B (multiple of 256)
     uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
     uint32_t *sortTotal;       // [1] entries in the sorted array
     float4 *sampleOut;         // [capacity] finished colour per output slot

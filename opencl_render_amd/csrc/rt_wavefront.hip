@@ -83,6 +83,18 @@ __device__ __forceinline__ bool pair_test_flat(const float4 r0, const float4 r1,
     return (tri != excluded) & (tmin < t) & (t < tmax) & (0 <= l1) & (0 <= l2) & (l1 + l2 <= 1.f);
 }
 
+// The answer of a traced ray from its hitKey: the winning (cell, triangle) pair is evaluated once more with the ray's own
+// limits, which reproduces t, l1, l2 bit for bit (the running maximum of :366-379 only ever rejected other candidates).
+__device__ __forceinline__ uint32_t resolve_hit(const RtDevScene &S, unsigned long long key, V3 o, V3 d, float tmin, float tmax,
+                                                uint32_t excluded, float &t, float &l1, float &l2)
+{
+    if (key == ~0ull) return RT_NONE;
+    const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key;
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    pair_test_flat(r0, r1, r2, r3, o, d, tmin, tmax, excluded, t, l1, l2);
+    return __float_as_uint(r0.w);
+}
+
 #ifdef RT_DIAG_STAMPS
 // Diagnostic build only (never shipped, outputs untouched): shader-clock stamps, summed per wave into S.stats.
 __device__ __forceinline__ unsigned long long diag_stamp()
@@ -199,6 +211,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
         if (gid < RT_WF_QSHARDS) W.counts[((round + 2) % 3) * RT_WF_QSHARDS + gid] = 0u;
         if (gid < RT_WF_SORT_COPIES * RT_WF_SORT_BINS) W.sortHist[gid] = 0u;
+        if (gid == 0) W.sortExtra[0] = 0u;
     }
     const bool multiLight = S.lightCount > 1u;
 
@@ -218,9 +231,14 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
 
         if (live) {
             a = W.reqX[in][q].y;
-            const uint4 r = W.res[q];
-            uint32_t res_tri = r.x;
-            float res_t = __uint_as_float(r.y), res_l1 = __uint_as_float(r.z), res_l2 = __uint_as_float(r.w);
+            // round 0 consumes the primary hits (res); later rounds the keys the trace kernel left (hitKey), resolved below
+            uint32_t res_tri = RT_NONE;
+            float res_t = 0.f, res_l1 = 0.f, res_l2 = 0.f;
+            unsigned long long key = ~0ull;
+            if (round == 0u) {
+                const uint4 r = W.res[q];
+                res_tri = r.x; res_t = __uint_as_float(r.y); res_l1 = __uint_as_float(r.z); res_l2 = __uint_as_float(r.w);
+            } else key = W.hitKey[q];
 
             uint64_t rng = W.rng[a];
             const uint4 meta = W.meta[a];
@@ -233,10 +251,10 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             int laIndex = (int)((meta.z >> 12) & 15u);
             uint32_t j = meta.z >> 16;
             float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
-            uint4 laAns = make_uint4(RT_NONE, 0u, 0u, 0u);
+            unsigned long long laKey = ~0ull;
             bool laFetched = false;
-            if (laState == 1u) { laAns = W.res[W.laSlot[a]]; laState = 2u; laFetched = true; }
-            else if (laState == 2u) laAns = W.laRes[a];
+            if (laState == 1u) { laKey = W.hitKey[W.laSlot[a]]; laState = 2u; laFetched = true; }
+            else if (laState == 2u) laKey = W.laKey[a];
 
             // the ray in flight (ring slot `head`), loaded when its answer is here
             V3 cur_o = mk(0, 0, 0), cur_d = mk(0, 0, 0), cur_w = mk(0, 0, 0);
@@ -261,12 +279,14 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 const float4 qo = W.reqO[in][q], qd = W.reqD[in][q];
                 where = xyz(qo); lmin = qo.w; toL = xyz(qd); lmax = qd.w;
                 if (multiLight) { n = xyz(W.shN[a]); rngL = W.rngL[a]; }
+                res_tri = resolve_hit(S, key, where, toL, lmin, lmax, hit_tri, res_t, res_l1, res_l2);
                 pc = PC_SHADOW_RESULT;
             } else {
                 const float4 c0 = ringA[head * 3 + 0], c1 = ringA[head * 3 + 1], c2 = ringA[head * 3 + 2];
                 cur_o = xyz(c0); cur_tmin = c0.w; cur_d = xyz(c1); cur_excl = __float_as_uint(c1.w); cur_w = xyz(c2);
                 cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
                 cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
+                if (round != 0u) res_tri = resolve_hit(S, key, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
             }
             bool finished = false, shadedNow = false, rngDirty = false, outDirty = false;
             uint32_t emitStage = WS_RAY;
@@ -438,7 +458,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         res_tri = camera_scan(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         pc = PC_RAY_RESULT;
                     } else if (laState == 2u && laIndex == head) { // traced ahead of time: the answer is already here
-                        res_tri = laAns.x; res_t = __uint_as_float(laAns.y); res_l1 = __uint_as_float(laAns.z); res_l2 = __uint_as_float(laAns.w);
+                        res_tri = resolve_hit(S, laKey, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         laState = 0u;
                         pc = PC_RAY_RESULT;
                     } else {
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 if (outDirty) W.outc[a] = pack4(out, 0.f);
                 W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | ((attStored ? 1u : 0u) << 9) |
                                                        (laState << 10) | ((uint32_t)laIndex << 12) | (j << 16), hit_tri);
-                if (laState == 2u && laFetched) W.laRes[a] = laAns;
+                if (laState == 2u && laFetched) W.laKey[a] = laKey;
                 if (emitStage == WS_SHADOW) {
                     W.shP[a] = pack4(P, ndl);
                     W.shFace[a] = pack4(face, front ? 1.f : 0.f);
@@ -497,19 +517,75 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
     }
 }
 
-// ---- stage 2b: length-sorted trace input ---------------------------------------------------------------------------
-// A round lasts as long as its longest wave, and a wave as long as its longest ray (walks have 1..766 cell visits, 167 on
-// average).  Where a ray LEAVES the grid is cheap to compute (three divides and three plane searches), and for a ray that
-// hits nothing that gives its exact number of cell visits.  wf_setup_kernel turns every request into a self-contained
-// entry (the DDA start state of raytrace_opencl.c:351-362,383-385, computed once here instead of in the trace kernel),
-// keys it by predicted visits and counts it into RT_WF_SORT_BINS classes; wf_scatter_kernel moves the entries to their
-// sorted positions, longest class first.  Waves then hold rays of similar length (lane utilisation of the walk) and the
-// workgroups with the longest walks are dispatched first (the round no longer ends with a few stragglers).  Only the
-// ORDER in which rays are traced changes; every ray's arithmetic is untouched.
+// ---- stage 2b: segmented, length-sorted trace input -----------------------------------------------------------------
+// A round lasts as long as its longest dependent chain: a ray that crosses the whole grid makes 766 cell visits one after
+// the other, and measured round times are ~0.4 ms + 0.32 ms per million rays -- the constant is that chain.  The walk is a
+// 3-way merge: per axis, the parameters T_a(i) = (plane_a[i] - o_a) / d_a at which the ray crosses successive planes form a
+// non-decreasing sequence (the same rounded quotients the reference computes, :383-385), and every step takes the smallest
+// head (:387-398).  So the state of the walk after all crossings with T <= tau is, per axis, simply the NUMBER of such
+// crossings -- it can be computed without walking (a plane search plus two exact divides per axis), for any tau.  A long
+// ray is therefore cut into up to RT_WF_MAXSEG SEGMENTS at parameters tau_k: segment k starts in the state at tau_k and ends
+// when it has visited the start cell of segment k+1 (the existing end-cell rule, :380).  Segments are traced as independent
+// entries; the ray's answer is the hit of its lowest segment that has one (atomicMin on hitKey), exactly the first cell
+// with a hit in path order.  Segments after a hit are wasted work; the chain per entry is ~8x shorter.
+//
+// wf_setup_kernel turns every request into its entries (DDA start state computed once, here instead of in the trace
+// kernel), keys them by predicted cell visits and counts them into RT_WF_SORT_BINS classes; wf_scatter_kernel moves the
+// entries to their sorted positions, longest class first.  Only the ORDER and GROUPING in which cells are visited changes.
+// Cutting costs work (every entry has a start-up and a test batch of its own, segments behind a hit are wasted), so the
+// aimed-at cell visits per segment depend on how many rays the round has: a round that fills the GPU several times over is
+// only relieved of its very longest chains, a round with few rays is cut finely enough to occupy every SIMD.
+#ifndef RT_WF_SEG_BIG
+#define RT_WF_SEG_BIG 4096 // rounds with >= RT_WF_RAYS_BIG rays: longer than any walk, i.e. no cutting -- such a round is bound by its
+                           // total work, and cutting at 384/256/192/128 visits measured 1-13 % slower (more entries, wasted segments)
+#endif
+#ifndef RT_WF_SEG_MID
+#define RT_WF_SEG_MID 128
+#endif
+#ifndef RT_WF_SEG_SMALL
+#define RT_WF_SEG_SMALL 64 // rounds with < RT_WF_RAYS_MID rays
+#endif
+#ifndef RT_WF_RAYS_BIG
+#define RT_WF_RAYS_BIG 400000u
+#endif
+#ifndef RT_WF_RAYS_MID
+#define RT_WF_RAYS_MID 150000u
+#endif
+#ifndef RT_WF_MAXSEG
+#define RT_WF_MAXSEG 12
+#endif
+struct DdaState { uint32_t cell; float dx, dy, dz; };
+
+// One axis of the state at parameter tau: c0 = cell coordinate of the walk's start, returns the coordinate after all
+// crossings with T <= tau and, in `head`, the parameter of the next crossing.  `limit` = crossings that stay inside the grid.
+__device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t c0, float oa, float da, float tau, float &head)
+{
+    const bool pos = (0.f <= da);
+    const int limit = pos ? (int)(RT_GRID_DIV - 1 - c0) : (int)c0; // the crossing after these leaves the grid (tau is before it)
+    // guess from the position (the plane search of GetBoxAddress), then settle it with the exact quotients
+    const float p = oa + tau * da;
+    int g = 0;
+#pragma unroll
+    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2)
+        if (planes[g + div] < p) g += div;
+    int m = pos ? g - (int)c0 : (int)c0 - g;
+    m = m < 0 ? 0 : (m > limit ? limit : m);
+    // crossing number k (1-based) is plane c0+k going up, c0-k+1 going down
+    while (m >= 1 && !((planes[pos ? (int)c0 + m : (int)c0 - m + 1] - oa) / da <= tau)) --m;
+    float next = (planes[pos ? (int)c0 + m + 1 : (int)c0 - m] - oa) / da;
+    while (m < limit && next <= tau) {
+        ++m;
+        next = (planes[pos ? (int)c0 + m + 1 : (int)c0 - m] - oa) / da;
+    }
+    head = next;
+    return pos ? c0 + (uint32_t)m : c0 - (uint32_t)m;
+}
+
 __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
+    __shared__ uint32_t extraWave[4], extraBase, raysWave[4];
     const uint32_t blocksPerShard = W.shardCap >> 8; // grid: RT_WF_QSHARDS queue slices x workgroups per slice
     const uint32_t shard = blockIdx.x / blocksPerShard;
     const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
@@ -517,7 +593,16 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     if (local0 >= total) return; // whole workgroup beyond the slice's entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     if (threadIdx.x < RT_WF_SORT_BINS) binCount[threadIdx.x] = 0u;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    { // rays of the whole round: sum of the RT_WF_QSHARDS queue lengths (two per thread)
+        uint32_t n = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x] + W.counts[(round % 3) * RT_WF_QSHARDS + 256 + threadIdx.x];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+        if (lane == 0) raysWave[wave] = n;
+    }
     __syncthreads();
+    const uint32_t roundRays = raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3];
+    const uint32_t segLen = roundRays >= RT_WF_RAYS_BIG ? RT_WF_SEG_BIG : (roundRays >= RT_WF_RAYS_MID ? RT_WF_SEG_MID : RT_WF_SEG_SMALL);
 
     const uint32_t in = round & 1;
     const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;
@@ -526,9 +611,12 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
     const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
-    float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    uint32_t excluded = RT_NONE, cell = 0, endCell = 0xffffffffu, bin = 0, rank = 0;
+    float tmin = 0.f, tmax = 0.f, te = RT_INF;
+    uint32_t excluded = RT_NONE, endCell = 0xffffffffu, lastCell = 0, visits = 1, nseg = 0;
+    DdaState cur;
+    cur.cell = 0; cur.dx = 0.f; cur.dy = 0.f; cur.dz = 0.f;
     if (active) {
+        W.hitKey[mine] = ~0ull; // no segment of this request has a hit yet
         const float4 ro = W.reqO[in][mine], rd = W.reqD[in][mine];
         o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
         excluded = W.reqX[in][mine].x;
@@ -542,17 +630,16 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
             if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
             if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
         }
-        cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
+        cur.cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
         V3 to;
         if (tmax < RT_INF) {
             to = along(o, tmax, d);
             bind_in_cube(to, d, lo, hi);
         } else {
-            // scheduling key only: the point where the ray leaves the grid (never used for the result)
-            float te = RT_INF;
-            if (d.x != 0.f) { const float t = (((0.f < d.x) ? hi.x : lo.x) - o.x) / d.x; if (t < te) te = t; }
-            if (d.y != 0.f) { const float t = (((0.f < d.y) ? hi.y : lo.y) - o.y) / d.y; if (t < te) te = t; }
-            if (d.z != 0.f) { const float t = (((0.f < d.z) ? hi.z : lo.z) - o.z) / d.z; if (t < te) te = t; }
+            // where the ray leaves the grid: the smallest of the three boundary crossings (same quotients as the walk's)
+            if (d.x != 0.f) { const float t = (((0.f <= d.x) ? hi.x : lo.x) - o.x) / d.x; if (t < te) te = t; }
+            if (d.y != 0.f) { const float t = (((0.f <= d.y) ? hi.y : lo.y) - o.y) / d.y; if (t < te) te = t; }
+            if (d.z != 0.f) { const float t = (((0.f <= d.z) ? hi.z : lo.z) - o.z) / d.z; if (t < te) te = t; }
             to = (te < RT_INF) ? along(o, te, d) : from;
         }
 #pragma unroll
@@ -561,16 +648,84 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
             if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
             if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
         }
-        if (tmax < RT_INF) endCell = (uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16);
+        lastCell = (uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16); // scheduling only, unless the ray has an end cell
+        if (tmax < RT_INF) endCell = lastCell;
         // distances from the ray ORIGIN to the next plane of each axis (:383-385)
-        dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
-        dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
-        dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
+        cur.dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
+        cur.dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
+        cur.dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
         // every step moves one axis by one cell in a fixed direction: visits = Manhattan distance + 1
-        uint32_t visits = (uint32_t)(abs(ex - cx) + abs(ey - cy) + abs(ez - cz)) + 1u;
-        if (visits > 767u) visits = 767u;
-        bin = (767u - visits) / 12u;
-        rank = atomicAdd(&binCount[bin], 1u);
+        visits = (uint32_t)(abs(ex - cx) + abs(ey - cy) + abs(ez - cz)) + 1u;
+        nseg = 1;
+        // Only rays without an end cell are cut, and only where every quotient involved is an ordinary number (a zero
+        // direction component makes heads infinite or NaN and the merge argument is not worth stretching to them).
+        const float ta = fminf(cur.dx, fminf(cur.dy, cur.dz));
+        const bool plain = !(tmax < RT_INF) && d.x != 0.f && d.y != 0.f && d.z != 0.f && te < RT_INF && -RT_INF < ta && ta < te &&
+                           cur.dx == cur.dx && cur.dy == cur.dy && cur.dz == cur.dz && cur.dx < RT_INF && cur.dy < RT_INF && cur.dz < RT_INF;
+        if (plain && visits > segLen + segLen / 4) { // a ray only slightly over the aim is left whole
+            nseg = (visits + segLen - 1) / segLen;
+            if (nseg > RT_WF_MAXSEG) nseg = RT_WF_MAXSEG;
+        }
+    }
+    // room for the extra entries (segments 1..) of this workgroup's rays: one atomic per workgroup; no room, no cutting
+    uint32_t extraAt = 0;
+    {
+        const uint32_t mineExtra = nseg ? nseg - 1u : 0u;
+        uint32_t incl = mineExtra;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += up;
+        }
+        if (lane == 63) extraWave[wave] = incl;
+        __syncthreads();
+        const uint32_t sum = extraWave[0] + extraWave[1] + extraWave[2] + extraWave[3];
+        if (threadIdx.x == 0) {
+            uint32_t at = sum ? atomicAdd(&W.sortExtra[0], sum) : 0u;
+            if (at + sum > W.extraCap) { if (sum) atomicSub(&W.sortExtra[0], sum); at = 0xffffffffu; }
+            extraBase = at;
+        }
+        __syncthreads();
+        uint32_t before = incl - mineExtra;
+        for (uint32_t w = 0; w < wave; ++w) before += extraWave[w];
+        if (extraBase == 0xffffffffu) { if (nseg > 1) nseg = 1; }
+        else extraAt = 2u * W.capacity + extraBase + before; // region B of the entry arrays starts after the 2*capacity queue slots
+    }
+    // the entries of this lane's ray: segment k goes from the state at tau_k to the start cell of segment k+1
+    const float ta = fminf(cur.dx, fminf(cur.dy, cur.dz));
+    const uint32_t perSeg = nseg ? (visits + nseg - 1) / nseg : 1u;
+    for (uint32_t k = 0; k < nseg; ++k) {
+        DdaState nxt = cur;
+        uint32_t segEnd = endCell;
+        bool last = (k + 1 == nseg);
+        if (!last) {
+            const float tau = ta + (te - ta) * ((float)(k + 1) / (float)nseg);
+            if (ta <= tau && tau < te) {
+                const uint32_t c0 = cur.cell & 255u, c1 = (cur.cell >> 8) & 255u, c2 = cur.cell >> 16;
+                // crossings already made by `cur` have T <= tau_k <= tau, so counting from cur's cell is counting from the start
+                const uint32_t nx = axis_state_at(planes, c0, o.x, d.x, tau, nxt.dx);
+                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), c1, o.y, d.y, tau, nxt.dy);
+                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), c2, o.z, d.z, tau, nxt.dz);
+                nxt.cell = nx | (ny << 8) | (nz << 16);
+                segEnd = nxt.cell;
+            } else last = true; // rounding left no room for another cut: this segment runs to the end
+        }
+        uint32_t v = last ? visits - perSeg * k : perSeg; // scheduling key only
+        if ((int)v < 1) v = 1;
+        if (v > 767u) v = 767u;
+        // two scales: segments of a finely cut round differ by a few visits, uncut rays by hundreds; bin 0 = longest
+        const uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+        const uint32_t rank = atomicAdd(&binCount[bin], 1u);
+        uint4 *e = W.stageEnt + 4 * (size_t)(k == 0 ? mine : extraAt + k - 1);
+        e[0] = make_uint4(mine, cur.cell | ((bin | (copy << 6)) << 24), segEnd, excluded);
+        e[1] = make_uint4(__float_as_uint(cur.dx), __float_as_uint(cur.dy), __float_as_uint(cur.dz), __float_as_uint(tmin));
+        e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+        e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank | (k << 24)); // rank inside this workgroup's bin for now
+        cur = nxt;
+        if (last) { // unused tail of the reservation: empty entries the scatter kernel drops
+            for (uint32_t r = k + 1; r < nseg; ++r) W.stageEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            break;
+        }
     }
     __syncthreads();
     if (threadIdx.x < RT_WF_SORT_BINS) {
@@ -578,23 +733,38 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         binBase[threadIdx.x] = n ? atomicAdd(&W.sortHist[copy * RT_WF_SORT_BINS + threadIdx.x], n) : 0u;
     }
     __syncthreads();
-    if (active) {
-        uint4 *stagingOut = W.stageEnt + 4 * (size_t)mine;
-        stagingOut[0] = make_uint4(mine, cell | ((bin | (copy << 6)) << 24), endCell, excluded);
-        stagingOut[1] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(tmin));
-        stagingOut[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-        stagingOut[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), binBase[bin] + rank);
+    // second visit: rank inside the (bin, copy) class = this workgroup's base + rank inside the workgroup
+    for (uint32_t k = 0; k < nseg; ++k) {
+        uint4 *e = W.stageEnt + 4 * (size_t)(k == 0 ? mine : extraAt + k - 1);
+        const uint32_t tag = e[0].y >> 24;
+        if (e[0].x == 0xffffffffu) break;
+        const uint32_t w = e[3].w;
+        W.sortRank[k == 0 ? mine : extraAt + k - 1] = binBase[tag & 63u] + (w & 0xffffffu);
     }
 }
 
-__global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round)
+// grid: the queue slices' workgroups (region A: segment 0 of every request, in queue order) followed by extraBlocks workgroups
+// over region B (further segments, densely packed)
+__global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round, const uint32_t queueBlocks)
 {
     __shared__ uint32_t base[RT_WF_SORT_BINS * RT_WF_SORT_COPIES];
-    const uint32_t blocksPerShard = W.shardCap >> 8;
-    const uint32_t shard = blockIdx.x / blocksPerShard;
-    const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
-    const uint32_t total = W.counts[(round % 3) * RT_WF_QSHARDS + shard];
-    if (local0 >= total && blockIdx.x != 0) return; // workgroup 0 always publishes the total
+    uint32_t mine = 0;
+    bool valid = false;
+    if (blockIdx.x < queueBlocks) {
+        const uint32_t blocksPerShard = W.shardCap >> 8;
+        const uint32_t shard = blockIdx.x / blocksPerShard;
+        const uint32_t local0 = (blockIdx.x - shard * blocksPerShard) * 256;
+        const uint32_t total = W.counts[(round % 3) * RT_WF_QSHARDS + shard];
+        if (local0 >= total && blockIdx.x != 0) return; // workgroup 0 always publishes the total
+        valid = local0 + threadIdx.x < total;
+        mine = shard * W.shardCap + local0 + threadIdx.x;
+    } else {
+        const uint32_t local0 = (blockIdx.x - queueBlocks) * 256;
+        const uint32_t total = W.sortExtra[0];
+        if (local0 >= total) return;
+        valid = local0 + threadIdx.x < total;
+        mine = 2u * W.capacity + local0 + threadIdx.x;
+    }
     if (threadIdx.x < RT_WF_SORT_BINS) { // one wave: exclusive prefix over (bin, copy), bin-major
         uint32_t h[RT_WF_SORT_COPIES], sum = 0;
 #pragma unroll
@@ -611,16 +781,18 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
         if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) W.sortTotal[0] = incl;
     }
     __syncthreads();
-    if (local0 + threadIdx.x < total) {
-        const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;
+    if (valid) {
         const uint4 *stagingIn = W.stageEnt + 4 * (size_t)mine;
-        uint4 e0 = stagingIn[0], e1 = stagingIn[1], e2 = stagingIn[2], e3 = stagingIn[3];
-        const uint32_t tag = e0.y >> 24; // bin | copy << 6
-        const uint32_t at = base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + e3.w;
-        e0.y &= 0xffffffu;
-        e3.w = 0u;
-        uint4 *sortedOut = W.sortedEnt + 4 * (size_t)at;
-        sortedOut[0] = e0; sortedOut[1] = e1; sortedOut[2] = e2; sortedOut[3] = e3;
+        uint4 e0 = stagingIn[0];
+        if (e0.x != 0xffffffffu) { // not an unused reservation
+            uint4 e1 = stagingIn[1], e2 = stagingIn[2], e3 = stagingIn[3];
+            const uint32_t tag = e0.y >> 24; // bin | copy << 6
+            const uint32_t at = base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + W.sortRank[mine];
+            e0.y &= 0xffffffu;
+            e3.w >>= 24; // segment number
+            uint4 *sortedOut = W.sortedEnt + 4 * (size_t)at;
+            sortedOut[0] = e0; sortedOut[1] = e1; sortedOut[2] = e2; sortedOut[3] = e3;
+        }
     }
 }
 
@@ -667,7 +839,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t mine = local0 + threadIdx.x;
     bool active = mine < total;
-    uint32_t q = 0, excluded = RT_NONE, cell = 0, endCell = 0xffffffffu;
+    uint32_t q = 0, excluded = RT_NONE, cell = 0, endCell = 0xffffffffu, seg = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
     if (active) {
@@ -677,6 +849,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
         o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
         d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+        seg = c3.w;
     }
     // per-axis step constants (:387-398): direction of travel is fixed per ray
     const bool px = (0.f <= d.x), py = (0.f <= d.y), pz = (0.f <= d.z);
@@ -846,12 +1019,8 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 __builtin_amdgcn_wave_barrier();
                 if (mineN) {
                     const unsigned long long key = keys[lane];
-                    if (key != ~0ull) { // the owner re-evaluates the winning pair: t, l1, l2 bit for bit
-                        const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(uint32_t)key;
-                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                        float t, l1, l2;
-                        pair_test_flat(r0, r1, r2, r3, o, d, tmin, tmax, excluded, t, l1, l2);
-                        W.res[q] = make_uint4(__float_as_uint(r0.w), __float_as_uint(t), __float_as_uint(l1), __float_as_uint(l2));
+                    if (key != ~0ull) { // this segment's hit: the ray's answer is that of its lowest segment with one
+                        atomicMin(&W.hitKey[q], ((unsigned long long)seg << 32) | (key & 0xffffffffull));
                         active = false;
                         walkEnded = true;
                     }
@@ -863,10 +1032,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dgTest += diag_stamp() - dgT0;
 #endif
-        if (active && walkEnded) { // walked to the end without a hit
-            W.res[q] = make_uint4(RT_NONE, __float_as_uint(tmax), 0u, 0u);
-            active = false;
-        }
+        if (active && walkEnded) active = false; // walked to the end without a hit: hitKey[q] stays as it is
         if (spins > RT_WF_SPIN_LIMIT || __ballot(active) == 0ull) break;
     }
 #ifdef RT_DIAG_STAMPS
@@ -919,11 +1085,13 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
     return hipGetLastError();
 }
 
-// setup + scatter of one round's requests: one workgroup per 256 entries of every queue slice (surplus groups exit at once)
+// setup + scatter of one round's requests: `blocks` = one workgroup per 256 entries of every queue slice (surplus groups exit at
+// once); the scatter also covers the region of extra segments
 extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
 {
+    const uint32_t extraBlocks = (wf->extraCap + 255u) / 256u;
     hipLaunchKernelGGL(wf_setup_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
-    hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round);
+    hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks + extraBlocks), dim3(256), 0, stream, *wf, round, blocks);
     return hipGetLastError();
 }
 
