@@ -533,24 +533,9 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
 // kernel), keys them by predicted cell visits and counts them into RT_WF_SORT_BINS classes; wf_scatter_kernel moves the
 // entries to their sorted positions, longest class first.  Only the ORDER and GROUPING in which cells are visited changes.
 // Cutting costs work (every entry has a start-up and a test batch of its own, segments behind a hit are wasted), so the
-// aimed-at cell visits per segment depend on how many rays the round has: a round that fills the GPU several times over is
-// only relieved of its very longest chains, a round with few rays is cut finely enough to occupy every SIMD.
-#ifndef RT_WF_SEG_BIG
-#define RT_WF_SEG_BIG 4096 // rounds with >= RT_WF_RAYS_BIG rays: longer than any walk, i.e. no cutting -- such a round is bound by its
-                           // total work, and cutting at 384/256/192/128 visits measured 1-13 % slower (more entries, wasted segments)
-#endif
-#ifndef RT_WF_SEG_MID
-#define RT_WF_SEG_MID 128
-#endif
-#ifndef RT_WF_SEG_SMALL
-#define RT_WF_SEG_SMALL 64 // rounds with < RT_WF_RAYS_MID rays
-#endif
-#ifndef RT_WF_RAYS_BIG
-#define RT_WF_RAYS_BIG 400000u
-#endif
-#ifndef RT_WF_RAYS_MID
-#define RT_WF_RAYS_MID 150000u
-#endif
+// aimed-at cell visits per segment depend on how many rays the round has (RtWavefront::segLen/segRays, rt_api.cpp): a round
+// that fills the GPU several times over is bound by its total work and is not cut at all (cutting at 384/256/192/128 visits
+// measured 1-13 % slower), a round with few rays is cut finely enough to occupy every SIMD.
 #ifndef RT_WF_MAXSEG
 #define RT_WF_MAXSEG 12
 #endif
@@ -602,7 +587,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     }
     __syncthreads();
     const uint32_t roundRays = raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3];
-    const uint32_t segLen = roundRays >= RT_WF_RAYS_BIG ? RT_WF_SEG_BIG : (roundRays >= RT_WF_RAYS_MID ? RT_WF_SEG_MID : RT_WF_SEG_SMALL);
+    const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : W.segLen[2]);
 
     const uint32_t in = round & 1;
     const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;

@@ -188,3 +188,28 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
     r, g, b = R.render_resident(po, 0)
     assert set(np.unique(r).tolist()) <= {0, 65535} and np.array_equal(r, g) and np.array_equal(g, b)
     assert np.array_equal(r > 0, full[0] > 0)  # same jitter, same nearest hits: the lit mask is identical
+
+
+@pytest.mark.parametrize("env", [
+    {"RT_WF_SEG": "16,16,16", "RT_WF_SEG_RAYS": "1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
+    {"RT_WF_SEG": "40,24,8"},                              # finer still for small rounds
+    {"RT_WF_SEG": "4096,4096,4096"},                       # never cut
+    {"RT_WF_LOOKAHEAD": "0"},                              # one ray in flight per path
+    {"RT_WF_GROUPS": "3"},                                 # three concurrent tile groups per instance
+    {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16", "RT_WF_SEG_RAYS": "1,1", "RT_WF_LOOKAHEAD": "0"},
+])
+def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
+    """Ray segmentation (the DDA state at a ray parameter is computed without walking, segments are traced independently and
+    combined by the lowest segment with a hit), the look-ahead ray and the tile groups only change WHEN cells are visited.
+    Golden scenes cover mirrors (rays through the whole grid), transparency chains (finite shadow rays, never cut) and
+    wrapping UVs; the big soup has walks of several hundred cells."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("mirror_hall", "mixed_materials_textured", "all_light_types", "degenerate_and_outside", "spot_finite_range"):
+        sc, want = load_golden_scene(name)
+        assert_planes(R.render_resident(sc, 0), want, f"{name} with {env}")
+    sc = S.make_soup(640, 360, 60_000, 0.012, seed=77, samples=2)
+    R.build_lists(sc)
+    got = R.render_resident(sc, 0)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    assert_planes(got, want, f"640x360 soup with {env}")
