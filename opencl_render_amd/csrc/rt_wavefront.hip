@@ -39,9 +39,58 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Triangle test on a per-triangle record that is already in registers (rt_device.h: a | ab | ac | n | abab abac acac inv),
+// branch-free like pair_test_flat below: same operations and operands as tri_test for every lane whose plane distance is in
+// range, the others discard the second half.
+__device__ __forceinline__ bool tri_rec_test_flat(const float4 r0, const float4 r1, const float4 r2, const float4 r3, V3 o, V3 d, float tmin,
+                                                  float tmax, float &t, float &l1, float &l2)
+{
+    const V3 a = mk(r0.x, r0.y, r0.z), ab = mk(r0.w, r1.x, r1.y), ac = mk(r1.z, r1.w, r2.x), n = mk(r2.y, r2.z, r2.w);
+    const V3 ao = sub3(o, a);
+    t = -dot3(n, ao) / dot3(n, d);
+    const V3 ap = sub3(along(o, t, d), a);
+    const float ap_ab = dot3(ap, ab);
+    const float ap_ac = dot3(ap, ac);
+    l1 = (r3.y * ap_ac - r3.z * ap_ab) * r3.w;
+    l2 = (r3.y * ap_ab - r3.x * ap_ac) * r3.w;
+    return (tmin < t) & (t < tmax) & (0 <= l1) & (0 <= l2) & (l1 + l2 <= 1.f);
+}
+
 // Nearest hit among the pixel's candidate list (raytrace_opencl.c:514-528): running maximum, ties keep the earliest.
+// Two candidates per step: their list entries were requested a step ahead, their records are requested together, so a
+// pixel with one or two candidates (the common case) costs three dependent round trips: range, list, records.
 __device__ __forceinline__ uint32_t camera_scan(const RtDevScene &S, uint32_t localPixel, V3 o, V3 d, float tmin, float tmax,
                                                 uint32_t excluded, float &hit_t, float &hit_l1, float &hit_l2)
+{
+    uint32_t hit_tri = RT_NONE;
+    hit_t = tmax;
+    const uint32_t first = S.camStart[localPixel], last = S.camEnd[localPixel];
+    const float4 *recs = reinterpret_cast<const float4 *>(S.triRec);
+    uint32_t t0 = (first < last) ? S.camList[first] : RT_NONE;
+    uint32_t t1 = (first + 1 < last) ? S.camList[first + 1] : RT_NONE;
+    for (uint32_t i = first; i < last; i += 2) {
+        const bool two = i + 1 < last;
+        const float4 *ra = recs + 4 * (size_t)t0, *rb = recs + 4 * (size_t)(two ? t1 : t0);
+        const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
+        const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
+        const uint32_t n0 = (i + 2 < last) ? S.camList[i + 2] : RT_NONE;
+        const uint32_t n1 = (i + 3 < last) ? S.camList[i + 3] : RT_NONE;
+        float t, l1, l2;
+        if (tri_rec_test_flat(a0, a1, a2, a3, o, d, tmin, hit_t, t, l1, l2) & (excluded != t0)) {
+            hit_t = t; hit_tri = t0; hit_l1 = l1; hit_l2 = l2;
+        }
+        if (tri_rec_test_flat(b0, b1, b2, b3, o, d, tmin, hit_t, t, l1, l2) & (excluded != t1) & two) {
+            hit_t = t; hit_tri = t1; hit_l1 = l1; hit_l2 = l2;
+        }
+        t0 = n0; t1 = n1;
+    }
+    return hit_tri;
+}
+
+// The same scan without the pipelining, for the logic kernel's rare camera-type continuation rays (:707-722), where
+// registers matter more than round trips.
+__device__ __forceinline__ uint32_t camera_scan_compact(const RtDevScene &S, uint32_t localPixel, V3 o, V3 d, float tmin, float tmax,
+                                                     uint32_t excluded, float &hit_t, float &hit_l1, float &hit_l2)
 {
     uint32_t hit_tri = RT_NONE;
     hit_t = tmax;
@@ -192,7 +241,7 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 // nothing touches `out` between a hit's shading and its :647-651), P is the product (1-out)*weight*(1-transparency)*texture
 // of :649-651 in the reference's order, and of face[2] only the entry :647 will pick is tracked.
 #ifndef RT_WF_LOGIC_WAVES
-#define RT_WF_LOGIC_WAVES 2
+#define RT_WF_LOGIC_WAVES 3
 #endif
 __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
 {
@@ -455,7 +504,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
                     cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
                     if (cur_fromCamera) {
-                        res_tri = camera_scan(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
+                        res_tri = camera_scan_compact(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         pc = PC_RAY_RESULT;
                     } else if (laState == 2u && laIndex == head) { // traced ahead of time: the answer is already here
                         res_tri = resolve_hit(S, laKey, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
