@@ -193,7 +193,7 @@ def main():
         # dominant kernel: the grid trace (wf_trace_kernel); its share of the byte model is the grid terms
         b_trace = 8.0 * stats["gridCells"] + 68.0 * stats["gridCandidates"]
         if pipeline and stage_ms["trace"] > 0 and b_trace > 0:
-            dom_name, dom_ms, dom_bytes = "wf_trace_kernel (all rounds of one frame)", stage_ms["trace"], b_trace
+            dom_name, dom_ms, dom_bytes = "wf_trace_kernel (all launches of one frame)", stage_ms["trace"], b_trace
         elif pipeline:
             dom_name, dom_ms, dom_bytes = "wf_primary_kernel", stage_ms["primary"], 20.0 * stats["primarySamples"] + 68.0 * stats["primaryCandidates"]
         else:
@@ -204,8 +204,8 @@ def main():
         # only reported when that profile is of this very workload and N=1
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic_lambert1m.json")))
-            key = dom_name.split(" ")[0] + ("<true>" if dom_name.startswith("wf_trace") else "")
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic_lambert1m.json")))
+            key = dom_name.split(" ")[0]
             if world == 1 and pipeline and prof.get("workload") == args.workload and args.samples == 1 and key in prof["per_frame"]:
                 traffic = int(prof["per_frame"][key]["hbm_bytes"])
         except (OSError, ValueError, KeyError):
