@@ -392,7 +392,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         if (const char *b = getenv("RT_WF_LOOKAHEAD")) lookAhead = (b[0] != '0') ? 1u : 0u;
         const bool multiLight = d->lightCount > 1;
         // segment lengths by round size (rt_wavefront.hip, wf_setup_kernel); 4096 is longer than any walk = no cutting
-        uint32_t segLen[3] = { 4096u, 128u, 64u }, segRays[2] = { 400000u, 150000u };
+        uint32_t segLen[4] = { 4096u, 256u, 128u, 64u }, segRays[3] = { 700000u, 300000u, 150000u };
         auto parse_list = [](const char *b, uint32_t *out, int n) {
             for (int i = 0; i < n && b && *b; ++i) {
                 char *endp = nullptr;
@@ -402,8 +402,8 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 b = (*endp == ',') ? endp + 1 : endp;
             }
         };
-        parse_list(getenv("RT_WF_SEG"), segLen, 3);
-        parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 2);
+        parse_list(getenv("RT_WF_SEG"), segLen, 4);
+        parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
         HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
         sc->groups.resize(groupCount);
         for (uint32_t g = 0; g < groupCount; ++g) {
@@ -427,8 +427,8 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             Wf.capacity = (uint32_t)cap;
             Wf.shardCap = (uint32_t)shardCap;
             Wf.lookAhead = lookAhead;
-            for (int i = 0; i < 3; ++i) Wf.segLen[i] = segLen[i];
-            for (int i = 0; i < 2; ++i) Wf.segRays[i] = segRays[i];
+            for (int i = 0; i < 4; ++i) Wf.segLen[i] = segLen[i];
+            for (int i = 0; i < 3; ++i) Wf.segRays[i] = segRays[i];
             const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
             const uint64_t extraCap = qcap; // room for the extra segments of long rays (a round that would need more cuts fewer rays)
             const uint64_t ecap = qcap + extraCap;

@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
 // Cutting costs work (every entry has a start-up and a test batch of its own, segments behind a hit are wasted), so the
 // aimed-at cell visits per segment depend on how many rays the round has (RtWavefront::segLen/segRays, rt_api.cpp): a round
 // that fills the GPU several times over is bound by its total work and is not cut at all (cutting at 384/256/192/128 visits
-// measured 1-13 % slower), a round with few rays is cut finely enough to occupy every SIMD.
+// measured 1-13 % slower), a round with few rays is cut finely enough to occupy every SIMD.  The levels were tuned on the
+// tile shares of 1, 2, 4 and 8 ranks (scripts/sweep_seg.sh); finer cuts than these move more time into this kernel than
+// they take out of the trace.
 #ifndef RT_WF_MAXSEG
 #define RT_WF_MAXSEG 12
 #endif
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     }
     __syncthreads();
     const uint32_t roundRays = raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3];
-    const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : W.segLen[2]);
+    const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : (roundRays >= W.segRays[2] ? W.segLen[2] : W.segLen[3]));
 
     const uint32_t in = round & 1;
     const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;

@@ -191,12 +191,12 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
 
 
 @pytest.mark.parametrize("env", [
-    {"RT_WF_SEG": "16,16,16", "RT_WF_SEG_RAYS": "1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
-    {"RT_WF_SEG": "40,24,8"},                              # finer still for small rounds
-    {"RT_WF_SEG": "4096,4096,4096"},                       # never cut
+    {"RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
+    {"RT_WF_SEG": "40,24,12,8"},                              # finer still for small rounds
+    {"RT_WF_SEG": "4096,4096,4096,4096"},                       # never cut
     {"RT_WF_LOOKAHEAD": "0"},                              # one ray in flight per path
     {"RT_WF_GROUPS": "3"},                                 # three concurrent tile groups per instance
-    {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16", "RT_WF_SEG_RAYS": "1,1", "RT_WF_LOOKAHEAD": "0"},
+    {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1", "RT_WF_LOOKAHEAD": "0"},
 ])
 def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
     """Ray segmentation (the DDA state at a ray parameter is computed without walking, segments are traced independently and
