@@ -392,7 +392,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         if (const char *b = getenv("RT_WF_LOOKAHEAD")) lookAhead = (b[0] != '0') ? 1u : 0u;
         const bool multiLight = d->lightCount > 1;
         // segment lengths by round size (rt_wavefront.hip, wf_setup_kernel); 4096 is longer than any walk = no cutting
-        uint32_t segLen[4] = { 4096u, 256u, 128u, 64u }, segRays[3] = { 700000u, 300000u, 150000u };
+        uint32_t segLen[4] = { 4096u, 256u, 64u, 16u }, segRays[3] = { 700000u, 300000u, 30000u };
         auto parse_list = [](const char *b, uint32_t *out, int n) {
             for (int i = 0; i < n && b && *b; ++i) {
                 char *endp = nullptr;

@@ -95,7 +95,7 @@ struct RtWavefront {
     uint32_t samplesInBatch;
     uint32_t lookAhead;      // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
     uint32_t segLen[4];      // aimed-at cell visits per segment for rounds with >= segRays[0] | >= segRays[1] | >= segRays[2] | fewer rays
-    uint32_t segRays[3];     // (RT_WF_SEG="a,b,c,d", RT_WF_SEG_RAYS="a,b,c"; defaults 4096,256,128,64 and 700000,300000,150000)
+    uint32_t segRays[3];     // (RT_WF_SEG="a,b,c,d", RT_WF_SEG_RAYS="a,b,c"; defaults 4096,256,64,16 and 700000,300000,30000)
     // per-path state, indexed by path id
     unsigned long long *rng; // generator state (raytrace_opencl.c:474-481), already moved past the current hit's light draws
     unsigned long long *rngL; // lightCount > 1 only: where the current hit's NEXT light set-up draws from

@@ -264,13 +264,20 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
     }
     const bool multiLight = S.lightCount > 1u;
 
-    // main requests only (slices [0, RT_WF_SHARDS)): one per waiting path; look-ahead answers are picked up by index
-    const uint32_t chunksPerShard = W.shardCap >> 6;
-    for (uint32_t chunk = waveId; chunk < RT_WF_SHARDS * chunksPerShard; chunk += waves) {
-        const uint32_t shard = chunk / chunksPerShard;
+    // main requests only (slices [0, RT_WF_SHARDS)): one per waiting path; look-ahead answers are picked up by index.
+    // Slices are sized for the worst case (every pixel a path) and filled evenly (round-robin shards), so the loop runs
+    // chunk-major up to the longest slice instead of over the whole capacity.
+    uint32_t longest = 0;
+#pragma unroll
+    for (int i = 0; i < RT_WF_SHARDS / 64; ++i) longest = max(longest, countIn[i * 64 + lane]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
+    const uint32_t usedChunks = (longest + 63u) >> 6;
+    for (uint32_t chunk = waveId; chunk < RT_WF_SHARDS * usedChunks; chunk += waves) {
+        const uint32_t shard = chunk % RT_WF_SHARDS, localChunk = chunk / RT_WF_SHARDS;
         const uint32_t total = countIn[shard];
-        const uint32_t local = (chunk - shard * chunksPerShard) * 64 + lane;
-        if ((chunk - shard * chunksPerShard) * 64 >= total) continue; // wave-uniform
+        const uint32_t local = localChunk * 64 + lane;
+        if (localChunk * 64 >= total) continue; // wave-uniform
         const uint32_t q = shard * W.shardCap + local;
         const bool live = local < total;
         bool emit = false, emitLa = false;
