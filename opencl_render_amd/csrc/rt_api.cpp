@@ -450,8 +450,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
             HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
             HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
-            G.queueBlocks = (uint32_t)(qcap / 256);  // one workgroup per 256 entries of every queue slice; surplus groups exit at once
-            G.traceBlocks = (uint32_t)(ecap / 256);  // one workgroup per 256 sorted entries
+            // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
+            G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // setup / scatter: two generations of 8 resident workgroups per CU
+            G.traceBlocks = (uint32_t)(ecap / 256); // trace: one workgroup per 256 sorted entries, dispatched in order; surplus groups exit at once
             G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
             if (G.logicBlocks == 0) G.logicBlocks = 1;
         }
