@@ -13,6 +13,7 @@ Workloads (synthetic seeded triangle soups, lists built by
     lambert_1m   1920x1080, 1M triangles (edge 0.004), white Lambert + 1 distant light, S=1   <- default, BASELINE metric
     primary_100k 1920x1080, 100k triangles (edge 0.01), luminance-only material, no lights (primary rays only)
     lambert_4k   3840x2160, 1M triangles (edge 0.004), as lambert_1m
+    lambert_10m_4k  3840x2160, 10M triangles (edge 0.0013), as lambert_1m (BASELINE config 5 on one GPU)
 One JSON line on stdout (rank 0); progress goes to stderr.
 """
 import argparse
@@ -30,6 +31,7 @@ WORKLOADS = {
     "lambert_1m": dict(width=1920, height=1080, triangles=1_000_000, edge=0.004, kind="lambert"),
     "primary_100k": dict(width=1920, height=1080, triangles=100_000, edge=0.01, kind="primary"),
     "lambert_4k": dict(width=3840, height=2160, triangles=1_000_000, edge=0.004, kind="lambert"),
+    "lambert_10m_4k": dict(width=3840, height=2160, triangles=10_000_000, edge=0.0013, kind="lambert"),
     "smoke": dict(width=256, height=256, triangles=10_000, edge=0.02, kind="lambert"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
@@ -116,6 +118,8 @@ def main():
     t0 = time.time()
     rs = R.ResidentScene(sc, local_rank, my_tiles)
     t_upload = time.time() - t0
+    if rank == 0:
+        log(f"scene resident on the device after {t_upload:.2f}s ({rs.device_bytes() / 1e9:.2f} GB)" if hasattr(rs, "device_bytes") else f"scene resident after {t_upload:.2f}s")
     buf_ptr, buf_bytes = rs.tile_buffer()
     tile_tensor = T.alias_device_bytes(buf_ptr, buf_bytes, device)
     stream = torch.cuda.current_stream(device).cuda_stream
@@ -156,6 +160,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        log(f"timed {args.steps} frames: {1e3 * elapsed / args.steps:.3f} ms/frame")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,6 +260,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O  # checker only: never part of the measured path
             rows = list(range(0, H, 1 if P * S <= 2_500_000 else 4))  # ~10 s single thread (the reference's C path is single-threaded)
+            log(f"CPU baseline + parity gate: {len(rows)} rows single-threaded, then the whole frame on all cores")
             t0 = time.perf_counter()
             bad = 0
             for y in rows:

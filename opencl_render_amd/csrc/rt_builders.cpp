@@ -305,15 +305,18 @@ int rtHipBuildSceneGrid(cl_uint vertexCount, cl_uint triangleCount, const cl_flo
     float (*bm)[4] = reinterpret_cast<float (*)[4]>(outBoxMin);
     std::memset(bm, 0, sizeof(float) * 4 * (DIV + 1));
 
-    // split planes at vertex quantiles, midway between neighbours (:657-678); index arithmetic is 32-bit
-    // unsigned like the reference's (it wraps above 2^24 vertices -- kept)
+    // split planes at vertex quantiles, midway between neighbours (:657-678).  The reference computes the quantile index
+    // (i * (vertexCount - 1)) / 256 in 32 bits, which wraps once vertexCount exceeds 2^24: its planes stop being monotone
+    // and nearly all triangles end up in a few cells (measured: 5.4 s per 4K frame at 10 M triangles).  The index is
+    // computed in 64 bits here -- the same value wherever the reference's does not overflow, the intended quantile where it
+    // does.  The lists are inputs of the hot path: its parity does not depend on this choice.
     if (0 < vertexCount) {
         std::vector<float> val(vertexCount);
         for (int w = 0; w < 3; ++w) {
             for (cl_uint v = 0; v < vertexCount; ++v) val[v] = vertex[v].s[w];
             std::sort(val.begin(), val.end());
             for (int i = 0; i < DIV + 1; ++i) {
-                cl_uint index = ((cl_uint)i * (vertexCount - 1)) / DIV;
+                const cl_uint index = (cl_uint)(((uint64_t)i * (uint64_t)(vertexCount - 1)) / (uint64_t)DIV);
                 if (0 < index && index < vertexCount) bm[i][w] = (val[index] + val[index - 1]) / 2.f;
                 else bm[i][w] = val[index];
             }
