@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <chrono>
 #include <vector>
 
 extern "C" hipError_t rtk_launch_trace(const RtDevScene *scene, int counted, hipStream_t stream);
@@ -130,6 +131,16 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
     if ((uint64_t)d->width * d->height > 0xffffffffull) return fail("image too large");
     HIP_OK(hipSetDevice(sc->device));
     HIP_OK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    // RT_HIP_TIMING=1: where the time of a scene upload goes (stderr)
+    const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    auto tLast = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(sc->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "libraytrace_hip: scene build: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tLast).count());
+        tLast = now;
+    };
 
     const uint32_t tilesX = (d->width + RT_TILE - 1) / RT_TILE, tilesY = (d->height + RT_TILE - 1) / RT_TILE;
     sc->width = d->width; sc->height = d->height; sc->tilesX = tilesX;
@@ -193,6 +204,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         else if (sc->upload(d->camList, d->camListSize, &D.camList, "camList")) return -1;
         HIP_OK(hipStreamSynchronize(sc->stream)); // staging vectors die here
     }
+    mark("camera lists");
     {
         const cl_uint *ids = nullptr;
         if (sc->upload(sc->tileIds.data(), nt, &ids, "tileIds")) return -1;
@@ -225,6 +237,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             if (d->triMaterial[t] >= (cl_int)d->materialCount) return fail("triangle %u uses material %d of %u", t, d->triMaterial[t], d->materialCount);
     }
 
+    mark("geometry");
     // --- grid ----------------------------------------------------------------------------------------------------
     {
         std::vector<float> planes(3 * (RT_GRID_DIV + 1));
@@ -241,6 +254,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             if (d->gridList[i] >= d->triangleCount) return fail("grid list entry %llu = %u is not a triangle (count %u)", (unsigned long long)i, d->gridList[i], d->triangleCount);
         if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
         if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
+        mark("grid checks + upload");
         std::vector<unsigned long long> bits((size_t)(RT_GRID_DIV / 4) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4), 0ull);
         for (uint32_t z = 0; z < RT_GRID_DIV; ++z)
             for (uint32_t y = 0; y < RT_GRID_DIV; ++y) {
@@ -251,6 +265,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                     if (d->gridStart[row + x] != d->gridStart[row + x + 1]) w[x >> 2] |= 1ull << (shift | (x & 3));
             }
         if (sc->upload(bits.data(), bits.size(), &D.gridBits, "gridBits")) return -1;
+        mark("occupancy words");
         // dense view: rank per block, first pair per non-empty cell (in block order, bit order inside a block), pairs
         {
             const size_t blocks = bits.size();
@@ -308,6 +323,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         HIP_OK(hipStreamSynchronize(sc->stream));
     }
 
+    mark("dense grid view");
     // --- materials -------------------------------------------------------------------------------------------------
     {
         D.materialCount = d->materialCount;
@@ -369,6 +385,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         HIP_OK(hipStreamSynchronize(sc->stream));
     }
 
+    mark("materials + lights");
     // --- wavefront pipeline buffers: worst case every pixel of every sample in a batch becomes a path ------------
     {
         if (d->lightCount >= 65536u) return fail("lightCount %u too large", d->lightCount);
@@ -457,6 +474,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             if (G.logicBlocks == 0) G.logicBlocks = 1;
         }
         HIP_OK(hipStreamSynchronize(sc->stream));
+        mark("path state buffers");
         const char *env = getenv("RT_HIP_PIPELINE");
         if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     }
