@@ -195,7 +195,7 @@ int rtHipRenderTiles(rtHipScene *scene, void *stream);
  *   WAVEFRONT (default) staged pipeline: primary -> rounds of (per-path logic, length sort of the new ray requests, grid
  *                       trace) -> ordered accumulate.  rtHipRenderTiles blocks until the frame's rounds have been issued.
  *                       Tuning aids read at scene creation: RT_WF_LOOKAHEAD=0|1, RT_WF_SEG="a,b,c,d" and
- *                       RT_WF_SEG_RAYS="a,b,c" (ray segmentation by round size), RT_WF_GROUPS=n, RT_WF_STATE_MB.
+ *                       RT_WF_SEG_RAYS="a,b,c" (ray segmentation by round size), RT_WF_APPEND_RAYS=n (rounds below n rays skip the length sort), RT_WF_GROUPS=n, RT_WF_STATE_MB.
  *   MEGAKERNEL          one launch, one thread per pixel (kept for A/B runs and for the work counters). */
 #define RT_HIP_PIPELINE_MEGAKERNEL 0
 #define RT_HIP_PIPELINE_WAVEFRONT  1

@@ -421,6 +421,8 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         };
         parse_list(getenv("RT_WF_SEG"), segLen, 4);
         parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
+        uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
+        if (const char *b = getenv("RT_WF_APPEND_RAYS")) appendRays = (uint32_t)strtoul(b, nullptr, 10);
         HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
         sc->groups.resize(groupCount);
         for (uint32_t g = 0; g < groupCount; ++g) {
@@ -446,6 +448,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             Wf.lookAhead = lookAhead;
             for (int i = 0; i < 4; ++i) Wf.segLen[i] = segLen[i];
             for (int i = 0; i < 3; ++i) Wf.segRays[i] = segRays[i];
+            Wf.appendRays = appendRays;
             const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
             const uint64_t extraCap = qcap; // room for the extra segments of long rays (a round that would need more cuts fewer rays)
             const uint64_t ecap = qcap + extraCap;
@@ -462,9 +465,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) ||
                 sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
                 sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
-                sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(1, &Wf.sortTotal))
+                sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal))
                 return -1;
-            HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, sizeof(uint32_t), sc->stream));
+            HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, 2 * sizeof(uint32_t), sc->stream));
             HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
             HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
             // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)

@@ -132,7 +132,8 @@ struct RtWavefront {
     uint32_t *sortExtra;       // [1] entries in region B this round
     uint32_t extraCap;         // capacity of region B (multiple of 256)
     uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
-    uint32_t *sortTotal;       // [1] entries in the sorted array
+    uint32_t *sortTotal;       // [2] entries at the front of the sorted array | 1 if the round was appended (region B holds entries too)
+    uint32_t appendRays;       // rounds with fewer rays than this skip the counting sort (RT_WF_APPEND_RAYS, default 150000)
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
         if (gid < RT_WF_QSHARDS) W.counts[((round + 2) % 3) * RT_WF_QSHARDS + gid] = 0u;
         if (gid < RT_WF_SORT_COPIES * RT_WF_SORT_BINS) W.sortHist[gid] = 0u;
-        if (gid == 0) W.sortExtra[0] = 0u;
+        if (gid == 0) { W.sortExtra[0] = 0u; W.sortTotal[0] = 0u; } // (a sorted round overwrites sortTotal in wf_scatter_kernel)
     }
     const bool multiLight = S.lightCount > 1u;
 
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
-    __shared__ uint32_t extraWave[4], extraBase, raysWave[4], longWave[4];
+    __shared__ uint32_t extraWave[4], extraBase, raysWave[4], longWave[4], actWave[4], actBase;
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     { // rays of the whole round and the longest queue slice: RT_WF_QSHARDS queue lengths, two per thread
@@ -642,6 +642,12 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     const uint32_t roundRays = raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3];
     const uint32_t longest = max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3]));
     const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : (roundRays >= W.segRays[2] ? W.segLen[2] : W.segLen[3]));
+    // A small round is cut into near-equal segments; ordering those by length buys nothing, and the two launches of the
+    // counting sort are a fixed ~50 us.  Such a round's entries are APPENDED straight to the trace input instead: segment 0 of
+    // every ray compactly at the front (sortTotal counts them), further segments in region B (sortExtra counts them), and
+    // wf_scatter_kernel finds nothing to do.
+    const bool append = roundRays < W.appendRays;
+    if (append && blockIdx.x == 0 && threadIdx.x == 0) W.sortTotal[1] = 1u; // tells the trace kernel that region B is in use
     // Queue slices are sized for the worst case and filled evenly, so the work items are (slice, 256-entry block) pairs up to the
     // longest slice, taken block-major by a fixed grid (a grid over the whole capacity is mostly workgroups that exit at once:
     // ~0.35 us per 1000 of them, a quarter of a millisecond per 4K frame).
@@ -742,6 +748,16 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         if (extraBase == 0xffffffffu) { if (nseg > 1) nseg = 1; }
         else extraAt = 2u * W.capacity + extraBase + before; // region B of the entry arrays starts after the 2*capacity queue slots
     }
+    uint32_t appendAt = 0; // append mode: where segment 0 of this lane's ray goes
+    if (append) {
+        const unsigned long long actMask = __ballot(active);
+        if (lane == 0) actWave[wave] = (uint32_t)__popcll(actMask);
+        __syncthreads();
+        if (threadIdx.x == 0) actBase = atomicAdd(&W.sortTotal[0], actWave[0] + actWave[1] + actWave[2] + actWave[3]);
+        __syncthreads();
+        appendAt = actBase + (uint32_t)__popcll(actMask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) appendAt += actWave[w];
+    }
     // the entries of this lane's ray: segment k goes from the state at tau_k to the start cell of segment k+1
     const float ta = fminf(cur.dx, fminf(cur.dy, cur.dz));
     const uint32_t perSeg = nseg ? (visits + nseg - 1) / nseg : 1u;
@@ -766,6 +782,19 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         if (v > 767u) v = 767u;
         // two scales: segments of a finely cut round differ by a few visits, uncut rays by hundreds; bin 0 = longest
         const uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+        if (append) { // final format, final place
+            uint4 *e = W.sortedEnt + 4 * (size_t)(k == 0 ? appendAt : extraAt + k - 1);
+            e[0] = make_uint4(mine, cur.cell, segEnd, excluded);
+            e[1] = make_uint4(__float_as_uint(cur.dx), __float_as_uint(cur.dy), __float_as_uint(cur.dz), __float_as_uint(tmin));
+            e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+            e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), k);
+            cur = nxt;
+            if (last) { // unused tail of the reservation: entries the trace kernel skips
+                for (uint32_t r = k + 1; r < nseg; ++r) W.sortedEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+                break;
+            }
+            continue;
+        }
         const uint32_t rank = atomicAdd(&binCount[bin], 1u);
         uint4 *e = W.stageEnt + 4 * (size_t)(k == 0 ? mine : extraAt + k - 1);
         e[0] = make_uint4(mine, cur.cell | ((bin | (copy << 6)) << 24), segEnd, excluded);
@@ -778,6 +807,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
             break;
         }
     }
+    if (append) continue; // workgroup-uniform: no ranks to settle
     __syncthreads();
     if (threadIdx.x < RT_WF_SORT_BINS) {
         const uint32_t n = binCount[threadIdx.x];
@@ -802,12 +832,16 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
     __shared__ uint32_t base[RT_WF_SORT_BINS * RT_WF_SORT_COPIES];
     __shared__ uint32_t longWave[4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t raysWave[4];
     {
-        uint32_t m = max(W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x], W.counts[(round % 3) * RT_WF_QSHARDS + 256 + threadIdx.x]);
+        const uint32_t c0 = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x], c1 = W.counts[(round % 3) * RT_WF_QSHARDS + 256 + threadIdx.x];
+        uint32_t m = max(c0, c1), n = c0 + c1;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-        if (lane == 0) longWave[wave] = m;
+        for (int off = 32; off >= 1; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off, 64)); n += __shfl_xor(n, off, 64); }
+        if (lane == 0) { longWave[wave] = m; raysWave[wave] = n; }
     }
+    __syncthreads();
+    if (raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3] < W.appendRays) return; // the round was appended by wf_setup_kernel
     if (threadIdx.x < RT_WF_SORT_BINS) { // one wave: exclusive prefix over (bin, copy), bin-major
         uint32_t h[RT_WF_SORT_COPIES], sum = 0;
 #pragma unroll
@@ -821,7 +855,7 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
         uint32_t at = incl - sum;
 #pragma unroll
         for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { base[threadIdx.x * RT_WF_SORT_COPIES + c] = at; at += h[c]; }
-        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) W.sortTotal[0] = incl;
+        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) { W.sortTotal[0] = incl; W.sortTotal[1] = 0u; } // all entries are in [0, total)
     }
     __syncthreads();
     const uint32_t usedBlocks = (max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3])) + 255u) >> 8;
@@ -891,8 +925,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     __shared__ uint8_t ownerOf[4][RT_WF_LEAN_LIST * 64];                // per wave: lane that recorded item c
     __shared__ unsigned long long keyOf[4][64];                         // per wave and lane: (cell order, pair index) of the earliest hit
 
+    // entries [0, total) and -- in an appended round -- the extra segments in region B, which follow in 64-entry chunks
     const uint32_t total = W.sortTotal[0];
-    if (blockIdx.x * 256 >= total) return; // whole workgroup beyond the entries
+    const uint32_t extra = W.sortTotal[1] ? W.sortExtra[0] : 0u;
+    const uint32_t chunksA = (total + 63u) >> 6, chunksB = (extra + 63u) >> 6;
+    if (blockIdx.x * 4 >= chunksA + chunksB) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
@@ -902,9 +939,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // cursor, were 23 % and 11 % slower; the price of this grid is ~0.35 us per 1000 workgroups that find nothing to do.)
     for (uint32_t once = 0; once < 1u; ++once) {
     const uint32_t chunk = blockIdx.x * 4 + wave;
-    if (chunk * 64 >= total) break;
-    const uint32_t mine = chunk * 64 + lane;
-    bool active = mine < total;
+    if (chunk >= chunksA + chunksB) break;
+    const bool inB = chunk >= chunksA;
+    const uint32_t mine = inB ? 2u * W.capacity + (chunk - chunksA) * 64 + lane : chunk * 64 + lane;
+    bool active = inB ? (chunk - chunksA) * 64 + lane < extra : mine < total;
     uint32_t q = 0, excluded = RT_NONE, cell = 0, endCell = 0xffffffffu, seg = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
@@ -912,6 +950,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         const uint4 *e = W.sortedEnt + 4 * (size_t)mine;
         const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
         q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
+        if (q == 0xffffffffu) active = false; // an unused reservation of an appended round
         dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
         o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
         d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));

@@ -194,6 +194,8 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
     {"RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
     {"RT_WF_SEG": "40,24,12,8"},                              # finer still for small rounds
     {"RT_WF_SEG": "4096,4096,4096,4096"},                       # never cut
+    {"RT_WF_APPEND_RAYS": "0"},                            # every round goes through the counting sort
+    {"RT_WF_APPEND_RAYS": "4000000000", "RT_WF_SEG": "24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1"},  # no round does, all rays cut
     {"RT_WF_LOOKAHEAD": "0"},                              # one ray in flight per path
     {"RT_WF_GROUPS": "3"},                                 # three concurrent tile groups per instance
     {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1", "RT_WF_LOOKAHEAD": "0"},
