@@ -311,8 +311,8 @@ int rtHipBuildSceneGrid(cl_uint vertexCount, cl_uint triangleCount, const cl_flo
     // computed in 64 bits here -- the same value wherever the reference's does not overflow, the intended quantile where it
     // does.  The lists are inputs of the hot path: its parity does not depend on this choice.
     if (0 < vertexCount) {
-        std::vector<float> val(vertexCount);
-        for (int w = 0; w < 3; ++w) {
+        auto axis = [&](int w) { // the three axes are independent: one thread each when threads are allowed
+            std::vector<float> val(vertexCount);
             for (cl_uint v = 0; v < vertexCount; ++v) val[v] = vertex[v].s[w];
             std::sort(val.begin(), val.end());
             for (int i = 0; i < DIV + 1; ++i) {
@@ -320,7 +320,12 @@ int rtHipBuildSceneGrid(cl_uint vertexCount, cl_uint triangleCount, const cl_flo
                 if (0 < index && index < vertexCount) bm[i][w] = (val[index] + val[index - 1]) / 2.f;
                 else bm[i][w] = val[index];
             }
-        }
+        };
+        if (hw_threads(threads) >= 3) {
+            std::thread tx(axis, 0), ty(axis, 1);
+            axis(2);
+            tx.join(); ty.join();
+        } else for (int w = 0; w < 3; ++w) axis(w);
     }
 
     const uint64_t CELLS = (uint64_t)DIV * DIV * DIV;
