@@ -13,6 +13,7 @@
 // pinned by restatement only ("parity unpinned" in DESIGN.md).  The trace kernel does not depend on that: any
 // lists are just inputs to it, and the oracle consumes the very same arrays.
 #include "raytrace_hip.h"
+#include "rt_build_shared.h"
 
 #include <algorithm>
 #include <atomic>
@@ -24,20 +25,16 @@
 
 namespace {
 
-struct F2 { float x, y; };
-struct F3 { float x, y, z; };
+using rtbuild::F2;
+using rtbuild::F3;
+using rtbuild::dot3;
+using rtbuild::cross3;
+using rtbuild::to_u32;
+using rtbuild::Camera;
+using rtbuild::camera_position;
+using rtbuild::fill_rectangle;
 
 inline F3 ld3(const cl_float3 &v) { return F3{ v.s[0], v.s[1], v.s[2] }; }
-inline float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }              // raytrace.c:18-20
-inline F3 cross3(F3 a, F3 b) { return F3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; } // :21-27
-
-// x86-64 float/double -> unsigned conversions as MSVC/gcc emit them (cvttss2si r64 + truncate to 32 bits):
-// negative values wrap, NaN/overflow give 0 in the low word.
-inline uint32_t to_u32(double v)
-{
-    if (!(v > -9223372036854775808.0 && v < 9223372036854775808.0)) return 0u;
-    return (uint32_t)(int64_t)v;
-}
 
 int hw_threads(int threads)
 {
@@ -58,68 +55,7 @@ template <class Fn> void parallel_chunks(int threads, uint64_t n, Fn fn)
     for (auto &th : pool) th.join();
 }
 
-// ---- camera lists -------------------------------------------------------------------------------------------
-
-struct Camera { F3 eye, topLeft, lr, tb; float pixelSizeInv; };
-
-// trianglelist.cpp:74-90
-F2 camera_position(const Camera &c, F3 v)
-{
-    float invSq = c.pixelSizeInv * c.pixelSizeInv;
-    F3 ev{ v.x - c.eye.x, v.y - c.eye.y, v.z - c.eye.z };
-    F3 sn = cross3(c.lr, c.tb);
-    float scale = dot3(c.topLeft, sn) / dot3(ev, sn);
-    F3 tv{ scale * ev.x - c.topLeft.x, scale * ev.y - c.topLeft.y, scale * ev.z - c.topLeft.z };
-    return F2{ dot3(c.lr, tv) * invSq, dot3(c.tb, tv) * invSq };
-}
-
-// trianglelist.cpp:131-217.  Calls emit(pixel) for every pixel whose candidate list receives the triangle.
-template <class Emit> void fill_rectangle(uint32_t W, uint32_t H, F2 a, F2 b, F2 c, Emit emit)
-{
-    F2 ab{ b.x - a.x, b.y - a.y }, bc{ c.x - b.x, c.y - b.y }, ca{ a.x - c.x, a.y - c.y };
-    // slopes; division by zero fails the edge tests by design (:143-150)
-    F2 abS, bcS, caS;
-    abS.x = ab.x / ab.y; abS.y = 1.f / abS.x;
-    bcS.x = bc.x / bc.y; bcS.y = 1.f / bcS.x;
-    caS.x = ca.x / ca.y; caS.y = 1.f / caS.x;
-
-    // bounding rectangle clipped to the image (:153-157); fmin/fmax are the double functions on promoted floats
-    uint32_t x0 = to_u32(std::fmax(0.0, std::fmin(std::fmin((double)a.x, (double)b.x), std::fmin((double)c.x, (double)(float)(W - 1)))));
-    uint32_t y0 = to_u32(std::fmax(0.0, std::fmin(std::fmin((double)a.y, (double)b.y), std::fmin((double)c.y, (double)(float)(H - 1)))));
-    uint32_t x1 = to_u32(std::fmin((double)(float)(W - 1), std::fmax(std::fmax((double)a.x, (double)b.x), std::fmax((double)c.x, 0.0))));
-    uint32_t y1 = to_u32(std::fmin((double)(float)(H - 1), std::fmax(std::fmax((double)a.y, (double)b.y), std::fmax((double)c.y, 0.0))));
-
-    const uint32_t ax = to_u32(std::floor((double)a.x)), ay = to_u32(std::floor((double)a.y));
-    // the pixel holding vertex a, if on screen (:160-162)
-    if (0.f <= a.x && a.x < (float)W && 0.f <= a.y && a.y < (float)H)
-        emit((uint64_t)std::floor((double)a.x) + (uint64_t)std::floor((double)a.y) * (uint64_t)W);
-
-    for (uint32_t x = x0; x <= x1; ++x) {
-        for (uint32_t y = y0; y <= y1; ++y) {
-            if (x == ax && y == ay) continue;
-            const float fx = (float)x, fy = (float)y;
-            // where each edge crosses this pixel's row/column lines (:169-181)
-            float ab0 = a.x + (fy - a.y) * abS.x, ab1 = a.y + (fx - a.x) * abS.y, ab2 = ab0 + abS.x, ab3 = ab1 + abS.y;
-            float bc0 = b.x + (fy - b.y) * bcS.x, bc1 = b.y + (fx - b.x) * bcS.y, bc2 = bc0 + bcS.x, bc3 = bc1 + bcS.y;
-            float ca0 = c.x + (fy - c.y) * caS.x, ca1 = c.y + (fx - c.x) * caS.y, ca2 = ca0 + caS.x, ca3 = ca1 + caS.y;
-            bool edge =
-                ((0.f <= (a.x - ab0) * (ab0 - b.x)) & (x == to_u32(ab0))) | ((0.f <= (a.x - ab2) * (ab2 - b.x)) & (x == to_u32(ab2))) |
-                ((0.f <= (a.y - ab1) * (ab1 - b.y)) & (y == to_u32(ab1))) | ((0.f <= (a.y - ab3) * (ab3 - b.y)) & (y == to_u32(ab3))) |
-                ((0.f <= (b.x - bc0) * (bc0 - c.x)) & (x == to_u32(bc0))) | ((0.f <= (b.x - bc2) * (bc2 - c.x)) & (x == to_u32(bc2))) |
-                ((0.f <= (b.y - bc1) * (bc1 - c.y)) & (y == to_u32(bc1))) | ((0.f <= (b.y - bc3) * (bc3 - c.y)) & (y == to_u32(bc3))) |
-                ((0.f <= (c.x - ca0) * (ca0 - a.x)) & (x == to_u32(ca0))) | ((0.f <= (c.x - ca2) * (ca2 - a.x)) & (x == to_u32(ca2))) |
-                ((0.f <= (c.y - ca1) * (ca1 - a.y)) & (y == to_u32(ca1))) | ((0.f <= (c.y - ca3) * (ca3 - a.y)) & (y == to_u32(ca3)));
-            if (edge) {
-                emit((uint64_t)x + (uint64_t)y * (uint64_t)W);
-            } else {
-                // pixel corner inside the triangle: same-sign cross products (:197-211)
-                float axx = fx - a.x, axy = fy - a.y, bxx = fx - b.x, bxy = fy - b.y, cxx = fx - c.x, cxy = fy - c.y;
-                float k1 = ab.x * axy - ab.y * axx, k2 = bc.x * bxy - bc.y * bxx, k3 = ca.x * cxy - ca.y * cxx;
-                if ((0 <= k1 * k2) & (0 <= k2 * k3)) emit((uint64_t)x + (uint64_t)y * (uint64_t)W);
-            }
-        }
-    }
-}
+// ---- camera lists: the arithmetic lives in rt_build_shared.h (shared with the device builder) ----------------
 
 // ---- scene grid ---------------------------------------------------------------------------------------------
 

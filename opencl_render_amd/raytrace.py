@@ -65,7 +65,7 @@ RESIDENT_SYMBOLS = [
     "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
-    "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildSceneGrid", "rtHipFree",
+    "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipFree",
 ]
 
 _lib = None
@@ -136,6 +136,8 @@ def lib() -> C.CDLL:
     L.rtHipBuildCameraList.argtypes = [u32, u32, vp, vp, vp, vp, f32, u32, vp, vp, C.c_int,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.rtHipBuildSceneGrid.argtypes = [u32, u32, vp, vp, C.c_int, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.rtHipBuildCameraListDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, vp, f32, u32, u32, vp, vp,
+                                             C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
     L.rtHipFree.argtypes = [vp]
     L.rtHipFree.restype = None
     _lib = L
@@ -183,6 +185,21 @@ def build_camera_list(sc: Scene, threads: int = 0) -> None:
     sc.cam_start = _take(ps, sc.pixels, np.uint32)
     sc.cam_end = _take(pe, sc.pixels, np.uint32)
     sc.cam_list = _take(pl, n.value, np.uint32)
+
+
+def build_camera_list_device(sc: Scene, device: int = 0) -> float:
+    """Camera lists built on the GPU (rt_build_device.hip); returns the device time of the build in ms."""
+    L = lib()
+    ps, pe, pl, n, ms = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_double()
+    rc = L.rtHipBuildCameraListDevice(device, sc.width, sc.height, _ptr(sc.eye), _ptr(sc.eye_to_top_left), _ptr(sc.left_to_right),
+                                      _ptr(sc.top_to_bottom), sc.pixel_size_inv, sc.vertex_count, sc.triangle_count, _ptr(sc.vertex),
+                                      _ptr(sc.tri_index), C.byref(ps), C.byref(pe), C.byref(pl), C.byref(n), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError(f"rtHipBuildCameraListDevice failed ({rc})")
+    sc.cam_start = _take(ps, sc.pixels, np.uint32)
+    sc.cam_end = _take(pe, sc.pixels, np.uint32)
+    sc.cam_list = _take(pl, n.value, np.uint32)
+    return ms.value
 
 
 def build_scene_grid(sc: Scene, threads: int = 0) -> None:
