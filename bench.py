@@ -110,9 +110,9 @@ def main():
         log(f"scene {sc.name}: {sc.width}x{sc.height}, T={sc.triangle_count}, cam list {len(sc.cam_list)} (mean K_p "
             f"{sc.sum_candidates() / sc.pixels:.2f}), grid list {len(sc.grid_list)}; host prep {time.time() - t0:.1f}s "
             f"(camera lists {sc.meta['t_cam_list_s']:.2f}s, grid {sc.meta['t_grid_s']:.2f}s)")
-    t_dev_cam = None
+    t_dev_cam = t_dev_grid = None
     if rank == 0 and not rehearse:
-        # the camera lists once more on the GPU (rt_build_device.hip; same lists up to storage sharing, tests/test_builders_gpu.py):
+        # both lists once more on the GPU (rt_build_device.hip; same lists as the host builders', tests/test_builders_gpu.py):
         # reported beside the host builder's time, the frame below uses the host-built lists
         import copy
         probe = copy.copy(sc)
@@ -120,6 +120,9 @@ def main():
         t0 = time.time()
         ms = R.build_camera_list_device(probe, local_rank)
         t_dev_cam = {"device_ms": round(ms, 3), "wall_s_with_transfers": round(time.time() - t0, 4)}
+        t0 = time.time()
+        ms = R.build_scene_grid_device(probe, local_rank)
+        t_dev_grid = {"device_ms": round(ms, 3), "wall_s_with_transfers": round(time.time() - t0, 4)}
         del probe
     if world > 1:
         sc = T.broadcast_scene(sc, rank, device)
@@ -255,7 +258,7 @@ def main():
             "work_counters": total_stats,
             "t_upload_s": round(t_upload, 3),
             "t_host_prep_s": {"camera_lists": round(sc.meta.get("t_cam_list_s", 0), 3), "grid": round(sc.meta.get("t_grid_s", 0), 3)},
-            "t_device_prep": {"camera_lists": t_dev_cam},
+            "t_device_prep": {"camera_lists": t_dev_cam, "grid": t_dev_grid},
         }
         # ---- CPU baseline + parity gate (rank 0, N=1 only): the oracle on a bounded sample of the same frame ------
         if world > 1 and rehearse:

@@ -259,6 +259,12 @@ int rtHipBuildSceneGrid(cl_uint vertexCount, cl_uint triangleCount, const cl_flo
                         int threads, cl_float3 outBoxMin[257], cl_uint **outStart, cl_uint **outList,
                         uint64_t *outListSize);
 
+/* The same grid built on a HIP device (rt_build_device.hip): split planes from radix-sorted coordinates, the flood fill of
+ * every triangle with the shared membership test (small triangles one thread each, big ones one workgroup each), pairs
+ * radix-sorted on cell << 32 | triangle.  Same planes, starts and lists as rtHipBuildSceneGrid.  No CPU fallback. */
+int rtHipBuildSceneGridDevice(int device, cl_uint vertexCount, cl_uint triangleCount, const cl_float3 *vertex, const cl_int3 *triIndex,
+                              cl_float3 outBoxMin[257], cl_uint **outStart, cl_uint **outList, uint64_t *outListSize, double *deviceMs);
+
 void rtHipFree(void *p);
 
 #ifdef __cplusplus

@@ -20,6 +20,7 @@
 #include "rt_build_shared.h"
 
 #include <chrono>
+#include <algorithm>
 #include <cstdlib>
 
 using rtbuild::Camera;
@@ -191,5 +192,289 @@ extern "C" int rtHipBuildCameraListDevice(int device, cl_uint W, cl_uint H, cons
         return -4;
     }
     *outStart = start; *outEnd = end; *outList = list; *outListSize = total;
+    return 0;
+}
+
+// ---- scene grid (counterpart of SceneTriangleList::New, trianglelist.cpp:655-737) ----------------------------------------
+// Split planes at the vertex quantiles per axis (:657-678, index in 64 bits as in rt_builders.cpp) from radix-sorted
+// coordinates; every triangle is flood-filled over the cells its clipped polygon touches, starting at the cell of vertex a
+// (FillCube :452-503 with BoxIntersectsTriangle / Cull from rt_build_shared.h).  The fill finds a SET of cells (the face-
+// connected component of cells that pass the test around the start cell), which does not depend on the order in which cells
+// are visited -- so a thread can do a small triangle on its own, and a workgroup can share a big one level by level.
+// (cell, triangle) pairs become 64-bit keys cell << 32 | triangle, radix-sorted: the lists come out cell-major with ascending
+// triangles, which is what the reference's sort on cell*T+tri gives (:707).
+#define RT_FILL_LOCAL 48u        // cells a thread's own fill may hold before the triangle is handed to a workgroup
+#define RT_FILL_QUEUE (1u << 22) // cells per workgroup fill
+#define RT_FILL_GROUPS 64u
+
+namespace {
+
+constexpr uint32_t GRID_CELLS = (uint32_t)rtbuild::DIV * rtbuild::DIV * rtbuild::DIV;
+
+__global__ __launch_bounds__(256) void grid_axis_values(uint32_t V, const float4 *__restrict__ vertex, float *__restrict__ vals)
+{
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float4 p = vertex[v];
+    vals[v] = p.x; vals[(size_t)V + v] = p.y; vals[2 * (size_t)V + v] = p.z;
+}
+
+__global__ void grid_planes(uint32_t V, const float *__restrict__ sorted, float *__restrict__ bm) // bm[257][4]
+{
+    const int i = threadIdx.x, w = blockIdx.x; // 257 threads x 3 axes
+    if (i > rtbuild::DIV) return;
+    const float *val = sorted + (size_t)w * V;
+    const uint32_t index = (uint32_t)(((uint64_t)i * (uint64_t)(V - 1)) / (uint64_t)rtbuild::DIV);
+    bm[4 * i + w] = (0 < index && index < V) ? (val[index] + val[index - 1]) / 2.f : val[index];
+}
+
+__device__ __forceinline__ F3 vtx(const float4 *vertex, int i) { const float4 v = vertex[i]; return F3{ v.x, v.y, v.z }; }
+
+// wave-aggregated append of n keys per lane; returns the lane's first slot
+__device__ __forceinline__ unsigned long long append_keys(unsigned long long *cursor, uint32_t n)
+{
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(cursor, (unsigned long long)total);
+    base = __shfl(base, 63, 64);
+    return base + incl - n;
+}
+
+__global__ __launch_bounds__(256) void grid_fill_small(uint32_t T, const float4 *__restrict__ vertex, const int4 *__restrict__ triIndex,
+                                                       const float *__restrict__ bmGlobal, unsigned long long *keys, unsigned long long *keyCursor,
+                                                       unsigned long long keyCap, uint32_t *bigList, uint32_t *bigCount, uint32_t *overflow)
+{
+    __shared__ float bm[rtbuild::DIV + 1][4];
+    for (int i = threadIdx.x; i < 4 * (rtbuild::DIV + 1); i += 256) (&bm[0][0])[i] = bmGlobal[i];
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t cells[RT_FILL_LOCAL];
+    uint32_t n = 0;
+    if (t < T) {
+        const int4 vi = triIndex[t];
+        const F3 a = vtx(vertex, vi.x), b = vtx(vertex, vi.y), c = vtx(vertex, vi.z);
+        int cell[3];
+        rtbuild::box_address(bm, a, cell);
+        cells[n++] = (uint32_t)cell[0] + (uint32_t)cell[1] * rtbuild::DIV + (uint32_t)cell[2] * rtbuild::DIV * rtbuild::DIV;
+        bool big = false;
+        for (uint32_t cur = 0; cur < n && !big; ++cur) {
+            const uint32_t id = cells[cur];
+            cell[2] = (int)(id / (rtbuild::DIV * rtbuild::DIV));
+            cell[1] = (int)((id % (rtbuild::DIV * rtbuild::DIV)) / rtbuild::DIV);
+            cell[0] = (int)(id % rtbuild::DIV);
+            float lo[3], hi[3];
+            for (int i = 0; i < 3; ++i) { lo[i] = bm[cell[i]][i]; hi[i] = bm[cell[i] + 1][i]; }
+            for (int i = 0; i < 3 && !big; ++i) {
+                for (int j = -1; j <= 1 && !big; j += 2) {
+                    cell[i] += j;
+                    if (0 <= cell[i] && cell[i] < rtbuild::DIV) {
+                        const uint32_t nid = (uint32_t)cell[0] + (uint32_t)cell[1] * rtbuild::DIV + (uint32_t)cell[2] * rtbuild::DIV * rtbuild::DIV;
+                        bool seen = false;
+                        for (uint32_t k = 0; k < n; ++k) seen |= (cells[k] == nid);
+                        if (!seen) {
+                            lo[i] = bm[cell[i]][i];
+                            hi[i] = bm[cell[i] + 1][i];
+                            if (rtbuild::box_hits_triangle(lo, hi, a, b, c)) {
+                                if (n == RT_FILL_LOCAL) big = true;
+                                else cells[n++] = nid;
+                            }
+                        }
+                    }
+                    cell[i] -= j;
+                }
+                lo[i] = bm[cell[i]][i];
+                hi[i] = bm[cell[i] + 1][i];
+            }
+        }
+        if (big) { bigList[atomicAdd(bigCount, 1u)] = t; n = 0; }
+    }
+    const unsigned long long at = append_keys(keyCursor, n); // every lane of the wave arrives here
+    if (at + n > keyCap) { if (n) atomicExch(overflow, 1u); return; }
+    for (uint32_t k = 0; k < n; ++k) keys[at + k] = ((unsigned long long)cells[k] << 32) | t;
+}
+
+__global__ __launch_bounds__(256) void grid_fill_big(const float4 *__restrict__ vertex, const int4 *__restrict__ triIndex, const float *__restrict__ bmGlobal,
+                                                     unsigned long long *keys, unsigned long long *keyCursor, unsigned long long keyCap,
+                                                     const uint32_t *__restrict__ bigList, const uint32_t *__restrict__ bigCount, uint32_t *bitmaps,
+                                                     uint32_t *queues, uint32_t *overflow)
+{
+    __shared__ float bm[rtbuild::DIV + 1][4];
+    __shared__ uint32_t qCount, levelStart, levelEnd;
+    __shared__ unsigned long long keyBase;
+    for (int i = threadIdx.x; i < 4 * (rtbuild::DIV + 1); i += 256) (&bm[0][0])[i] = bmGlobal[i];
+    uint32_t *bits = bitmaps + (size_t)blockIdx.x * (GRID_CELLS / 32); // all zero between triangles
+    uint32_t *queue = queues + (size_t)blockIdx.x * RT_FILL_QUEUE;
+    __syncthreads();
+    for (uint32_t bidx = blockIdx.x; bidx < bigCount[0]; bidx += gridDim.x) {
+        const uint32_t t = bigList[bidx];
+        const int4 vi = triIndex[t];
+        const F3 a = vtx(vertex, vi.x), b = vtx(vertex, vi.y), c = vtx(vertex, vi.z);
+        if (threadIdx.x == 0) {
+            int cell[3];
+            rtbuild::box_address(bm, a, cell);
+            const uint32_t id = (uint32_t)cell[0] + (uint32_t)cell[1] * rtbuild::DIV + (uint32_t)cell[2] * rtbuild::DIV * rtbuild::DIV;
+            bits[id >> 5] = 1u << (id & 31);
+            queue[0] = id;
+            qCount = 1; levelStart = 0; levelEnd = 1;
+        }
+        __syncthreads();
+        while (levelStart < levelEnd) { // workgroup-uniform
+            for (uint32_t q = levelStart + threadIdx.x; q < levelEnd; q += 256) {
+                const uint32_t id = queue[q];
+                int cell[3] = { (int)(id % rtbuild::DIV), (int)((id % (rtbuild::DIV * rtbuild::DIV)) / rtbuild::DIV), (int)(id / (rtbuild::DIV * rtbuild::DIV)) };
+                float lo[3], hi[3];
+                for (int i = 0; i < 3; ++i) { lo[i] = bm[cell[i]][i]; hi[i] = bm[cell[i] + 1][i]; }
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = -1; j <= 1; j += 2) {
+                        cell[i] += j;
+                        if (0 <= cell[i] && cell[i] < rtbuild::DIV) {
+                            const uint32_t nid = (uint32_t)cell[0] + (uint32_t)cell[1] * rtbuild::DIV + (uint32_t)cell[2] * rtbuild::DIV * rtbuild::DIV;
+                            const uint32_t mask = 1u << (nid & 31);
+                            if (!(__atomic_load_n(&bits[nid >> 5], __ATOMIC_RELAXED) & mask)) {
+                                lo[i] = bm[cell[i]][i];
+                                hi[i] = bm[cell[i] + 1][i];
+                                if (rtbuild::box_hits_triangle(lo, hi, a, b, c) && !(atomicOr(&bits[nid >> 5], mask) & mask)) {
+                                    const uint32_t pos = atomicAdd(&qCount, 1u);
+                                    if (pos < RT_FILL_QUEUE) queue[pos] = nid; else atomicExch(overflow, 2u);
+                                }
+                            }
+                        }
+                        cell[i] -= j;
+                    }
+                    lo[i] = bm[cell[i]][i];
+                    hi[i] = bm[cell[i] + 1][i];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (threadIdx.x == 0) { levelStart = levelEnd; levelEnd = qCount < RT_FILL_QUEUE ? qCount : RT_FILL_QUEUE; }
+            __syncthreads();
+        }
+        const uint32_t n = levelEnd;
+        if (threadIdx.x == 0) keyBase = atomicAdd(keyCursor, (unsigned long long)n);
+        __syncthreads();
+        const bool fits = keyBase + n <= keyCap;
+        if (!fits && threadIdx.x == 0) atomicExch(overflow, 1u);
+        for (uint32_t q = threadIdx.x; q < n; q += 256) {
+            const uint32_t id = queue[q];
+            if (fits) keys[keyBase + q] = ((unsigned long long)id << 32) | t;
+            bits[id >> 5] = 0u; // clear what this triangle set (a word may be cleared by several threads)
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_count_cells(unsigned long long n, const unsigned long long *__restrict__ keys, uint32_t *count)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&count[(uint32_t)(keys[i] >> 32)], 1u);
+}
+
+__global__ __launch_bounds__(256) void grid_write_list(unsigned long long n, const unsigned long long *__restrict__ keys, uint32_t *__restrict__ list,
+                                                       uint32_t *__restrict__ start)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) list[i] = (uint32_t)keys[i];
+    if (i == 0) start[GRID_CELLS] = (uint32_t)n; // the entry after the last cell (raytrace.c:441 relies on the +1 layout)
+}
+
+} // namespace
+
+extern "C" int rtHipBuildSceneGridDevice(int device, cl_uint vertexCount, cl_uint triangleCount, const cl_float3 *vertex, const cl_int3 *triIndex,
+                                         cl_float3 outBoxMin[257], cl_uint **outStart, cl_uint **outList, uint64_t *outListSize, double *deviceMs)
+{
+    if (!outBoxMin || !outStart || !outList || !outListSize) return -1;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || device < 0 || device >= nDev) return -5; // no CPU fallback: rtHipBuildSceneGrid is the host builder
+    BUILD_OK(hipSetDevice(device));
+    const uint32_t V = vertexCount, T = triangleCount;
+    for (uint32_t t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k)
+            if ((uint32_t)triIndex[t].s[k] >= V) return -6;
+    Buffers buf;
+    float4 *dVertex = nullptr; int4 *dIndex = nullptr;
+    float *dVals = nullptr, *dSorted = nullptr, *dBm = nullptr;
+    unsigned long long *dKeys = nullptr, *dKeysSorted = nullptr, *dCursor = nullptr;
+    uint32_t *dBigList = nullptr, *dBigCount = nullptr, *dOverflow = nullptr, *dBitmaps = nullptr, *dQueues = nullptr, *dStart = nullptr, *dCount = nullptr;
+    const unsigned long long keyCap = std::max<unsigned long long>(32ull * T, 1ull << 22);
+    BUILD_OK(buf.alloc(&dVertex, V)); BUILD_OK(buf.alloc(&dIndex, T));
+    BUILD_OK(buf.alloc(&dVals, (size_t)3 * V)); BUILD_OK(buf.alloc(&dSorted, (size_t)3 * V)); BUILD_OK(buf.alloc(&dBm, 4 * (rtbuild::DIV + 1)));
+    BUILD_OK(buf.alloc(&dKeys, keyCap)); BUILD_OK(buf.alloc(&dKeysSorted, keyCap)); BUILD_OK(buf.alloc(&dCursor, 1));
+    BUILD_OK(hipMemcpy(dVertex, vertex, (size_t)V * 16, hipMemcpyHostToDevice));
+    BUILD_OK(hipMemcpy(dIndex, triIndex, (size_t)T * 16, hipMemcpyHostToDevice));
+    Buffers buf2; // (Buffers holds ten pointers)
+    BUILD_OK(buf2.alloc(&dBigList, T)); BUILD_OK(buf2.alloc(&dBigCount, 1)); BUILD_OK(buf2.alloc(&dOverflow, 1));
+    BUILD_OK(buf2.alloc(&dBitmaps, (size_t)RT_FILL_GROUPS * (GRID_CELLS / 32))); BUILD_OK(buf2.alloc(&dQueues, (size_t)RT_FILL_GROUPS * RT_FILL_QUEUE));
+    BUILD_OK(buf2.alloc(&dStart, (size_t)GRID_CELLS + 1)); BUILD_OK(buf2.alloc(&dCount, (size_t)GRID_CELLS));
+    BUILD_OK(hipMemset(dBitmaps, 0, (size_t)RT_FILL_GROUPS * (GRID_CELLS / 32) * 4));
+    hipEvent_t e0, e1;
+    BUILD_OK(hipEventCreate(&e0)); BUILD_OK(hipEventCreate(&e1));
+    BUILD_OK(hipEventRecord(e0, nullptr));
+    BUILD_OK(hipMemsetAsync(dBm, 0, sizeof(float) * 4 * (rtbuild::DIV + 1), nullptr));
+    BUILD_OK(hipMemsetAsync(dCursor, 0, 8, nullptr));
+    BUILD_OK(hipMemsetAsync(dBigCount, 0, 4, nullptr));
+    BUILD_OK(hipMemsetAsync(dOverflow, 0, 4, nullptr));
+    BUILD_OK(hipMemsetAsync(dCount, 0, (size_t)GRID_CELLS * 4, nullptr));
+    Buffers buf3;
+    if (V) {
+        hipLaunchKernelGGL(grid_axis_values, dim3((V + 255) / 256), dim3(256), 0, nullptr, V, dVertex, dVals);
+        void *tmp = nullptr; size_t tmpBytes = 0;
+        BUILD_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmpBytes, dVals, dSorted, (int)V, 0, 32, nullptr));
+        BUILD_OK(buf3.alloc((char **)&tmp, tmpBytes));
+        for (int w = 0; w < 3; ++w)
+            BUILD_OK(hipcub::DeviceRadixSort::SortKeys(tmp, tmpBytes, dVals + (size_t)w * V, dSorted + (size_t)w * V, (int)V, 0, 32, nullptr));
+        hipLaunchKernelGGL(grid_planes, dim3(3), dim3(320), 0, nullptr, V, dSorted, dBm);
+    }
+    if (T) {
+        hipLaunchKernelGGL(grid_fill_small, dim3((T + 255) / 256), dim3(256), 0, nullptr, T, dVertex, dIndex, dBm, dKeys, dCursor, keyCap, dBigList,
+                           dBigCount, dOverflow);
+        hipLaunchKernelGGL(grid_fill_big, dim3(RT_FILL_GROUPS), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dKeys, dCursor, keyCap, dBigList, dBigCount,
+                           dBitmaps, dQueues, dOverflow);
+    }
+    unsigned long long n = 0;
+    uint32_t overflow = 0;
+    BUILD_OK(hipMemcpy(&n, dCursor, 8, hipMemcpyDeviceToHost));
+    BUILD_OK(hipMemcpy(&overflow, dOverflow, 4, hipMemcpyDeviceToHost));
+    if (overflow || n > keyCap) return -7; // more pairs than the key buffer or a fill larger than the workgroup queue
+    if (n > 0xffffffffull) return -3;
+    uint32_t *dList = nullptr;
+    BUILD_OK(buf3.alloc(&dList, (size_t)n));
+    if (n) {
+        void *tmp = nullptr; size_t tmpBytes = 0;
+        BUILD_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmpBytes, dKeys, dKeysSorted, (int)n, 0, 56, nullptr));
+        BUILD_OK(buf3.alloc((char **)&tmp, tmpBytes));
+        BUILD_OK(hipcub::DeviceRadixSort::SortKeys(tmp, tmpBytes, dKeys, dKeysSorted, (int)n, 0, 56, nullptr));
+        hipLaunchKernelGGL(grid_count_cells, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, nullptr, n, dKeysSorted, dCount);
+    }
+    {
+        void *tmp = nullptr; size_t tmpBytes = 0;
+        BUILD_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, dCount, dStart, (int)GRID_CELLS, nullptr));
+        BUILD_OK(buf3.alloc((char **)&tmp, tmpBytes));
+        BUILD_OK(hipcub::DeviceScan::ExclusiveSum(tmp, tmpBytes, dCount, dStart, (int)GRID_CELLS, nullptr));
+    }
+    hipLaunchKernelGGL(grid_write_list, dim3((uint32_t)((std::max<unsigned long long>(n, 1) + 255) / 256)), dim3(256), 0, nullptr, n, dKeysSorted, dList, dStart);
+    BUILD_OK(hipGetLastError());
+    BUILD_OK(hipEventRecord(e1, nullptr));
+    BUILD_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    BUILD_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (deviceMs) *deviceMs = ms;
+
+    cl_uint *start = (cl_uint *)std::malloc(((size_t)GRID_CELLS + 1) * 4), *list = (cl_uint *)std::malloc((size_t)(n ? n : 1) * 4);
+    if (!start || !list) { std::free(start); std::free(list); return -2; }
+    if (hipMemcpy(outBoxMin, dBm, sizeof(float) * 4 * (rtbuild::DIV + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(start, dStart, ((size_t)GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (n && hipMemcpy(list, dList, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+        std::free(start); std::free(list);
+        return -4;
+    }
+    *outStart = start; *outList = list; *outListSize = n;
     return 0;
 }

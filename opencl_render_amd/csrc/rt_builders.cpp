@@ -59,63 +59,11 @@ template <class Fn> void parallel_chunks(int threads, uint64_t n, Fn fn)
 
 // ---- scene grid ---------------------------------------------------------------------------------------------
 
-constexpr int DIV = 256; // trianglelist.h:110
+constexpr int DIV = rtbuild::DIV; // trianglelist.h:110
 
-// trianglelist.cpp:381-430 (Sutherland-Hodgman step with in-place insert, then removal of the outside points)
-bool cull(bool isMax, float limit, int dim, int *count, float poly[16][3])
-{
-    bool fresh[16] = { false };
-    for (int i = 0; i < *count; ++i) {
-        int nx = (i + 1) % *count;
-        float di = limit - poly[i][dim];
-        float dn = limit - poly[nx][dim];
-        if (di * dn < 0.f) {
-            float e0 = poly[nx][0] - poly[i][0], e1 = poly[nx][1] - poly[i][1], e2 = poly[nx][2] - poly[i][2];
-            float e[3] = { e0, e1, e2 };
-            float pct = di / e[dim];
-            int at = i + 1;
-            for (int j = (*count)++; at < j; --j) { poly[j][0] = poly[j - 1][0]; poly[j][1] = poly[j - 1][1]; poly[j][2] = poly[j - 1][2]; }
-            poly[at][0] = poly[i][0] + pct * e0;
-            poly[at][1] = poly[i][1] + pct * e1;
-            poly[at][2] = poly[i][2] + pct * e2;
-            fresh[at] = true;
-            i = at;
-        }
-    }
-    for (int i = 0; i < *count; ++i) {
-        bool outside = isMax ? (limit < poly[i][dim]) : (poly[i][dim] < limit);
-        if (!fresh[i] && outside) {
-            int k = (*count)--;
-            for (int j = i + 1; j < k; ++j) {
-                poly[j - 1][0] = poly[j][0]; poly[j - 1][1] = poly[j][1]; poly[j - 1][2] = poly[j][2];
-                fresh[j - 1] = fresh[j];
-            }
-            --i;
-        }
-    }
-    return 0 < *count;
-}
-
-// trianglelist.cpp:433-449
-bool box_hits_triangle(const float lo[3], const float hi[3], F3 a, F3 b, F3 c)
-{
-    int n = 3;
-    float poly[16][3] = { { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z } };
-    return cull(false, lo[0], 0, &n, poly) && cull(false, lo[1], 1, &n, poly) && cull(false, lo[2], 2, &n, poly) &&
-           cull(true, hi[0], 0, &n, poly) && cull(true, hi[1], 1, &n, poly) && cull(true, hi[2], 2, &n, poly);
-}
-
-// raytrace_opencl.c:174-193
-void box_address(const float (*bm)[4], F3 p, int cell[3])
-{
-    int cx = 0, cy = 0, cz = 0;
-    for (int div = DIV / 2; div >= 1; div /= 2) {
-        if (bm[cx + div][0] < p.x) cx += div;
-        if (bm[cy + div][1] < p.y) cy += div;
-        if (bm[cz + div][2] < p.z) cz += div;
-    }
-    cell[0] = cx; cell[1] = cy; cell[2] = cz;
-}
+// cull / box_hits_triangle / box_address: rt_build_shared.h (shared with the device builder)
+using rtbuild::box_hits_triangle;
+using rtbuild::box_address;
 
 // trianglelist.cpp:452-503: face-connected flood fill from the cell of vertex a.  `cells` receives the ids;
 // `bits` is a DIV^3-bit visited set, all-zero on entry and on exit.

@@ -65,7 +65,7 @@ RESIDENT_SYMBOLS = [
     "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
-    "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipFree",
+    "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
     L.rtHipBuildCameraList.argtypes = [u32, u32, vp, vp, vp, vp, f32, u32, vp, vp, C.c_int,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.rtHipBuildSceneGrid.argtypes = [u32, u32, vp, vp, C.c_int, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.rtHipBuildSceneGridDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
     L.rtHipBuildCameraListDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, vp, f32, u32, u32, vp, vp,
                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
     L.rtHipFree.argtypes = [vp]
@@ -213,6 +214,21 @@ def build_scene_grid(sc: Scene, threads: int = 0) -> None:
     sc.box_min = box
     sc.grid_start = _take(ps, GRID_DIV ** 3 + 1, np.uint32)
     sc.grid_list = _take(pl, n.value, np.uint32)
+
+
+def build_scene_grid_device(sc: Scene, device: int = 0) -> float:
+    """The scene grid built on the GPU (rt_build_device.hip); returns the device time of the build in ms."""
+    L = lib()
+    box = np.zeros((GRID_DIV + 1, 4), np.float32)
+    ps, pl, n, ms = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_double()
+    rc = L.rtHipBuildSceneGridDevice(device, sc.vertex_count, sc.triangle_count, _ptr(sc.vertex), _ptr(sc.tri_index), _ptr(box),
+                                     C.byref(ps), C.byref(pl), C.byref(n), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError(f"rtHipBuildSceneGridDevice failed ({rc})")
+    sc.box_min = box
+    sc.grid_start = _take(ps, GRID_DIV ** 3 + 1, np.uint32)
+    sc.grid_list = _take(pl, n.value, np.uint32)
+    return ms.value
 
 
 def build_lists(sc: Scene, threads: int = 0) -> Scene:

@@ -1,4 +1,4 @@
-"""GPU camera-list builder (rt_build_device.hip) against the host builder (rt_builders.cpp): the same triangles in the same
+"""GPU list builders (rt_build_device.hip) against the host builders (rt_builders.cpp).  Camera lists: the same triangles in the same
 pixels, every pixel's entries ascending.  Both compile the same arithmetic (rt_build_shared.h), so equality is exact; the
 host builder additionally lets equal neighbour lists share storage (the reference's de-duplication, trianglelist.cpp:580-613),
 which changes Start/End but not what a pixel's list holds."""
@@ -73,6 +73,26 @@ def test_device_camera_lists_equal_host_lists(w, h, tris, edge, seed, big):
     assert_same_lists(host, dev, f"{w}x{h}, {sc.triangle_count} triangles")
 
 
+@pytest.mark.parametrize("w,h,tris,edge,seed,big", [
+    (300, 200, 6000, 0.15, 5, False),      # triangles over a few cells each: the one-thread fill, some spill to the workgroup fill
+    (640, 360, 60_000, 0.012, 77, False),  # small triangles
+    (333, 177, 3000, 0.4, 9, True),        # triangles over thousands of cells: the workgroup fill
+    (1920, 1080, 100_000, 0.01, 12345, True),
+])
+def test_device_grid_equals_host_grid(w, h, tris, edge, seed, big):
+    sc = S.make_soup(w, h, tris, edge, seed=seed, samples=1)
+    if big:
+        sc = with_big_triangles(sc, seed)
+    host, dev = copy.copy(sc), copy.copy(sc)
+    R.build_scene_grid(host)
+    ms = R.build_scene_grid_device(dev, 0)
+    assert ms > 0
+    assert np.array_equal(host.box_min, dev.box_min), "split planes differ"
+    assert len(host.grid_list) == len(dev.grid_list), f"pair count {len(host.grid_list)} vs {len(dev.grid_list)}"
+    assert np.array_equal(host.grid_start, dev.grid_start), "cell starts differ"
+    assert np.array_equal(host.grid_list, dev.grid_list), "cell lists differ"
+
+
 def test_frame_from_device_built_lists_matches_oracle():
     """The hot path on device-built lists: same planes as the CPU oracle on the host-built lists."""
     import os
@@ -83,7 +103,7 @@ def test_frame_from_device_built_lists_matches_oracle():
     want = O.oracle_render(host, threads=os.cpu_count() or 1)
     dev = copy.copy(sc)
     R.build_camera_list_device(dev, 0)
-    R.build_scene_grid(dev)
+    R.build_scene_grid_device(dev, 0)
     got = R.render_resident(dev, 0)
     for ch, g, w in zip("RGB", got, want):
         assert np.array_equal(g, w), f"plane {ch}: {(g != w).sum()} values differ"
