@@ -297,7 +297,6 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             }
             std::vector<uint2> range(cellFirst.size() - 1);
             for (size_t k = 0; k + 1 < cellFirst.size(); ++k) range[k] = make_uint2(cellFirst[k], cellFirst[k + 1]);
-            if (sc->upload(block.data(), block.size(), &D.gridBlock, "gridBlock")) return -1;
             {
                 std::vector<uint32_t> sparse((size_t)3 * ((63u << 16 | 63u << 8 | 63u) + 1u), 0u);
                 for (size_t b = 0; b < blocks; ++b) {
@@ -462,7 +461,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
                 sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
                 sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
-                sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) ||
+                sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
                 sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
                 sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
                 sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal))

@@ -44,18 +44,17 @@ struct RtDevScene {
     // empty space without touching the 67 MB gridStart array; empty cells have no effect on the result.
     const unsigned long long *gridBits;
     // Dense view of the same grid for the wavefront trace kernel (no 67 MB sparse array, no list->record hop), shaped so
-    // a cell visit costs as few divergent load instructions as possible (the texture addresser is the bottleneck):
-    //   gridBlock[block]  {occupancy word lo, hi, rank}: rank = number of non-empty cells in all blocks before `block`
-    //                     (12 B, one dwordx3 load per block entered; 3 MiB, L2-resident)
-    //   dense cell id     k = rank + popcount(word & ((1<<bit)-1))
+    // a cell visit costs as few divergent load instructions as possible:
+    //   gridBlockSparse[i] {occupancy word lo, hi, rank}: rank = number of non-empty cells in all blocks before this one, blocks
+    //                     in the order (cx>>2) + 64*(cy>>2) + 4096*(cz>>2); 12 B per block, one dwordx2/x3 load.  The table
+    //                     is indexed SPARSELY by (cx>>2) | (cy>>2)<<8 | (cz>>2)<<16, so that the byte offset of a cell's
+    //                     block is 3*(cell & 0xFCFCFC) for a cell packed cx | cy<<8 | cz<<16 (two instructions):
+    //                     50 MB of address space, 3 MiB of touched lines
+    //   dense cell id     k = rank + popcount(word & ((1<<bit)-1)), bit = (cx&3) | (cy&3)<<2 | (cz&3)<<4
     //   cellRange[k]      {first, last} pair index range of the cell (one 8-byte load)
     //   pairRec[i]        64-byte record of pair i, replicated per (cell, triangle) pair so a cell's candidates are
     //                     contiguous: {a.xyz, triangleId} {n.xyz, -} {ab.xyz, abab} {ac.xyz, acac}
-    //                     (plane test = first two float4; abac and 1/(abac^2-abab*acac) are recomputed when needed)
-    const uint32_t *gridBlock;
-    // the same 12-byte entries, indexed SPARSELY by (cx>>2) | (cy>>2)<<8 | (cz>>2)<<16 so that the byte offset of a cell's
-    // block is 3*(cell & 0xFCFCFC) for a cell packed cx | cy<<8 | cz<<16 (wf_trace_sorted_kernel); 50 MB of address
-    // space, the same 3 MiB of touched lines
+    //                     (abac and 1/(abac^2-abab*acac) are recomputed in the test)
     const uint32_t *gridBlockSparse;
     const uint2 *cellRange;
     uint32_t cellCount; // non-empty cells = entries of cellRange
@@ -127,7 +126,8 @@ struct RtWavefront {
     // A long ray becomes several entries (SEGMENTS, rt_wavefront.hip): segment 0 sits at its request's queue index (region A,
     // [0, 2*capacity)), further segments are packed into region B ([2*capacity, 2*capacity + extraCap)).
     uint4 *stageEnt;           // [2*capacity + extraCap][4] entries, {.., cell | (bin | copy<<6)<<24, ..} .. {.., rank in workgroup | segment<<24}
-    uint4 *sortedEnt;          // [2*capacity + extraCap][4] entries in sorted order, {d.xyz, segment}
+    uint4 *sortedEnt;          // [2*capacity + extraCap][4] the entries of an APPENDED round (small rounds skip the sort), same layout
+    uint32_t *sortedIdx;       // [2*capacity + extraCap] a SORTED round: index into stageEnt of the entry at each sorted position
     uint32_t *sortRank;        // [2*capacity + extraCap] rank of the entry inside its (bin, copy) class
     uint32_t *sortExtra;       // [1] entries in region B this round
     uint32_t extraCap;         // capacity of region B (multiple of 256)

@@ -782,12 +782,12 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         if (v > 767u) v = 767u;
         // two scales: segments of a finely cut round differ by a few visits, uncut rays by hundreds; bin 0 = longest
         const uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
-        if (append) { // final format, final place
+        if (append) { // final place (same layout as a staged entry: no tag, segment in the top byte of the last word)
             uint4 *e = W.sortedEnt + 4 * (size_t)(k == 0 ? appendAt : extraAt + k - 1);
             e[0] = make_uint4(mine, cur.cell, segEnd, excluded);
             e[1] = make_uint4(__float_as_uint(cur.dx), __float_as_uint(cur.dy), __float_as_uint(cur.dz), __float_as_uint(tmin));
             e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-            e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), k);
+            e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), k << 24);
             cur = nxt;
             if (last) { // unused tail of the reservation: entries the trace kernel skips
                 for (uint32_t r = k + 1; r < nseg; ++r) W.sortedEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
@@ -876,16 +876,11 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
             mine = 2u * W.capacity + local;
         }
         if (valid) {
-            const uint4 *stagingIn = W.stageEnt + 4 * (size_t)mine;
-            uint4 e0 = stagingIn[0];
+            // only the ORDER is written: the trace kernel gathers its 64-byte entries from the staging array through it
+            const uint2 e0 = *reinterpret_cast<const uint2 *>(W.stageEnt + 4 * (size_t)mine); // {request, cell | tag << 24}
             if (e0.x != 0xffffffffu) { // not an unused reservation
-                uint4 e1 = stagingIn[1], e2 = stagingIn[2], e3 = stagingIn[3];
                 const uint32_t tag = e0.y >> 24; // bin | copy << 6
-                const uint32_t at = base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + W.sortRank[mine];
-                e0.y &= 0xffffffu;
-                e3.w >>= 24; // segment number
-                uint4 *sortedOut = W.sortedEnt + 4 * (size_t)at;
-                sortedOut[0] = e0; sortedOut[1] = e1; sortedOut[2] = e2; sortedOut[3] = e3;
+                W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + W.sortRank[mine]] = mine;
             }
         }
     }
@@ -927,7 +922,8 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
 
     // entries [0, total) and -- in an appended round -- the extra segments in region B, which follow in 64-entry chunks
     const uint32_t total = W.sortTotal[0];
-    const uint32_t extra = W.sortTotal[1] ? W.sortExtra[0] : 0u;
+    const bool appended = W.sortTotal[1] != 0u;
+    const uint32_t extra = appended ? W.sortExtra[0] : 0u;
     const uint32_t chunksA = (total + 63u) >> 6, chunksB = (extra + 63u) >> 6;
     if (blockIdx.x * 4 >= chunksA + chunksB) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
@@ -947,14 +943,15 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
     if (active) {
-        const uint4 *e = W.sortedEnt + 4 * (size_t)mine;
+        // a sorted round: position -> staging entry through sortedIdx; an appended round: the entry sits at the position itself
+        const uint4 *e = appended ? W.sortedEnt + 4 * (size_t)mine : W.stageEnt + 4 * (size_t)W.sortedIdx[mine];
         const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
-        q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
+        q = c0.x; cell = c0.y & 0xffffffu; endCell = c0.z; excluded = c0.w;
         if (q == 0xffffffffu) active = false; // an unused reservation of an appended round
         dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
         o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
         d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
-        seg = c3.w;
+        seg = c3.w >> 24;
     }
     // per-axis step constants (:387-398): direction of travel is fixed per ray
     const bool px = (0.f <= d.x), py = (0.f <= d.y), pz = (0.f <= d.z);
