@@ -139,24 +139,28 @@ def main():
     stream = torch.cuda.current_stream(device).cuda_stream
 
     planes = ids_dev = None
+    slots = T.max_tiles_per_rank(W, H, world)
     if rank == 0:
         planes = torch.zeros(3 * P * 2, dtype=torch.uint8, device=device)
-        ids_dev = [torch.from_numpy(R.tiles_of_rank(W, H, r, world).astype(np.int32)).to(device) for r in range(world)]
+        # The gathered buffer is [world][slots] tiles: ONE de-tiling launch over all of it.  Slot s of rank r holds tile
+        # ids[r][s]; padding slots get the first id past the grid, which the kernel drops at its height test.
+        ids = np.full((world, slots), R.tile_count(W, H), np.int32)
+        for r in range(world):
+            mine = R.tiles_of_rank(W, H, r, world).astype(np.int32)
+            ids[r, :len(mine)] = mine
+        ids_dev = torch.from_numpy(ids.reshape(-1)).to(device)
     L = R.lib()
 
     def frame():
         rs.render(stream)
         gathered = T.gather_tiles(tile_tensor, W, H, rank, world)
         if rank == 0:
-            planes.zero_()
+            planes.zero_()  # the kernel accumulates (saturating), like the ABI's planes
             base = planes.data_ptr()
-            for r in range(world):
-                n = ids_dev[r].numel()
-                if n:
-                    rc = L.rtHipDetile(local_rank, gathered[r].data_ptr(), ids_dev[r].data_ptr(), n, W, H,
-                                       base, base + 2 * P, base + 4 * P, stream)
-                    if rc != 0:
-                        raise RuntimeError("rtHipDetile: " + R.last_error())
+            rc = L.rtHipDetile(local_rank, gathered.data_ptr(), ids_dev.data_ptr(), world * slots, W, H,
+                               base, base + 2 * P, base + 4 * P, stream)
+            if rc != 0:
+                raise RuntimeError("rtHipDetile: " + R.last_error())
 
     def barrier():
         if world > 1:
