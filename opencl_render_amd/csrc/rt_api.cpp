@@ -847,7 +847,8 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     }
     const int n = rtHipDeviceCount();
     const bool all = (n > 1 && computationType == (cl_uint)n + 1);
-    if (n <= 0 || (!all && computationType > (cl_uint)n)) {
+    const bool virtualAll = n > 0 && computationType == (cl_uint)n + 1 && getenv("RT_HIP_VIRTUAL_DEVICES") && atoi(getenv("RT_HIP_VIRTUAL_DEVICES")) > 1;
+    if (n <= 0 || (!all && !virtualAll && computationType > (cl_uint)n)) {
         fail("RaytraceAll: computationType %u but %d HIP device(s) present", computationType, n);
         fprintf(stderr, "libraytrace_hip: %s\n", g_error.c_str());
         return CL_FALSE;
@@ -880,27 +881,42 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     memset(outputGreen, 0, P * sizeof(cl_ushort));
     memset(outputBlue, 0, P * sizeof(cl_ushort));
 
-    const int first = all ? 0 : (int)computationType - 1, count = all ? n : 1;
+    // "All GPUs": one scene per device with the tiles dealt round-robin, one host thread per device (a frame blocks its
+    // thread while the host looks at the ray queue between rounds, so the devices must not share one).
+    // RT_HIP_VIRTUAL_DEVICES=k (test hook): the all-GPUs id deals the tiles over k instances that share the real devices.
+    int virt = 0;
+    if (const char *b = getenv("RT_HIP_VIRTUAL_DEVICES")) virt = atoi(b);
+    const bool allVirtual = virt > 1 && computationType == (cl_uint)n + 1;
+    const bool every = all || allVirtual;
+    const int first = every ? 0 : (int)computationType - 1, count = allVirtual ? virt : (all ? n : 1);
     const uint32_t tiles = ((d.width + RT_TILE - 1) / RT_TILE) * ((d.height + RT_TILE - 1) / RT_TILE);
     std::vector<rtHipScene *> scenes((size_t)count, nullptr);
-    bool ok = true;
-    for (int g = 0; g < count && ok; ++g) {
-        std::vector<cl_uint> mine;
-        if (count > 1) {
-            for (uint32_t t = (uint32_t)g; t < tiles; t += (uint32_t)count) mine.push_back(t); // round-robin tile deal
-            if (mine.empty()) continue;
-        }
-        scenes[g] = rtHipSceneCreate(first + g, &d, mine.empty() ? nullptr : mine.data(), (cl_uint)mine.size());
-        ok = scenes[g] != nullptr;
-    }
+    std::vector<std::string> errors((size_t)count);
+    std::vector<char> failed((size_t)count, 0);
     g_progress.store(0.f, std::memory_order_relaxed);
     const long t0 = (long)clock();
     g_startTime.store(t0 ? t0 : 1, std::memory_order_relaxed); // must read non-zero once the kernel phase begins
     g_endTime.store(t0 ? t0 : 1, std::memory_order_relaxed);
-    for (int g = 0; g < count && ok; ++g)
-        if (scenes[g]) ok = rtHipRenderTiles(scenes[g], nullptr) == 0;
+    auto work = [&](int g) { // create + render one device's share; errors are thread-local, so they are carried out by hand
+        std::vector<cl_uint> mine;
+        if (count > 1) {
+            for (uint32_t t = (uint32_t)g; t < tiles; t += (uint32_t)count) mine.push_back(t); // round-robin tile deal
+            if (mine.empty()) return;
+        }
+        scenes[g] = rtHipSceneCreate((first + g) % n, &d, mine.empty() ? nullptr : mine.data(), (cl_uint)mine.size());
+        if (!scenes[g] || rtHipRenderTiles(scenes[g], nullptr) != 0 || rtHipSync(scenes[g], nullptr) != 0) { failed[g] = 1; errors[g] = g_error; }
+    };
+    if (count == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int g = 0; g < count; ++g) pool.emplace_back(work, g);
+        for (auto &t : pool) t.join();
+    }
+    bool ok = true;
+    for (int g = 0; g < count; ++g)
+        if (failed[g]) { ok = false; g_error = errors[g]; }
     int done = 0;
-    for (int g = 0; g < count && ok; ++g) {
+    for (int g = 0; g < count && ok; ++g) { // the planes are accumulated into by one thread
         if (!scenes[g]) continue;
         ok = rtHipReadback(scenes[g], outputRed, outputGreen, outputBlue) == 0;
         g_progress.store(0.999f * (float)++done / (float)count, std::memory_order_relaxed); // capped like raytrace.c:580

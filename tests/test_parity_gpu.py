@@ -215,3 +215,21 @@ def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
     got = R.render_resident(sc, 0)
     want = O.oracle_render(sc, threads=os.cpu_count() or 1)
     assert_planes(got, want, f"640x360 soup with {env}")
+
+
+def test_dropin_all_gpus_mode_threads_and_tile_deal(monkeypatch):
+    """RaytraceAll's extra id "all N GPUs (tiled)" (SURVEY 8b): one scene and one host thread per device, tiles dealt round
+    robin, the planes accumulated from every device's tile buffer.  RT_HIP_VIRTUAL_DEVICES deals the tiles over k instances
+    on the devices that are there, so the path runs on a one-GPU box."""
+    n = R.lib().rtHipDeviceCount()
+    for k in ("3", "5"):
+        monkeypatch.setenv("RT_HIP_VIRTUAL_DEVICES", k)
+        sc, want = load_golden_scene("odd_size_multi_tile")
+        ok, r, g, b = R.raytrace_all(n + 1, sc)
+        assert ok, R.last_error()
+        assert_planes((r, g, b), want, f"odd_size_multi_tile over {k} instances")
+    sc = S.make_soup(640, 360, 60_000, 0.012, seed=77, samples=2)  # 5 x 3 tiles
+    R.build_lists(sc)
+    ok, r, g, b = R.raytrace_all(n + 1, sc)
+    assert ok, R.last_error()
+    assert_planes((r, g, b), O.oracle_render(sc, threads=os.cpu_count() or 1), "640x360 soup over 5 instances")
