@@ -395,7 +395,13 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
         // result, staging + sorted entry
         const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + 6 * (2 * 64 + 4) + 16;
-        uint64_t budget = 6ull << 30; // bytes of path state per batch; HBM is 288 GB, this is about queue locality
+        // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
+        // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
+        uint64_t budget = 24ull << 30;
+        {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB / 3 < budget) budget = freeB / 3;
+        }
         if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
