@@ -225,6 +225,15 @@ template <bool COUNT>
 __device__ __forceinline__ V3 texel(const RtDevScene &S, const Shared &sh, int start, uint32_t w, uint32_t h, const float *uv,
                                     float l1, float l2, uint32_t &raw, Counters &cn)
 {
+    if (w == 1u && h == 1u) { // a one-texel map: u*(w-1) and v*(h-1) are 0 (or NaN, which converts to 0 here) whatever the uv
+        long long idx1 = (long long)start;
+        if (idx1 < 0) idx1 = 0;
+        if (idx1 >= (long long)S.texelCount) idx1 = (long long)S.texelCount - 1;
+        const uchar4 px1 = reinterpret_cast<const uchar4 *>(S.textures)[idx1];
+        if (COUNT) cn.v[ST_TEXELS]++;
+        raw = px1.x;
+        return mk(sh.unit255[px1.x], sh.unit255[px1.y], sh.unit255[px1.z]);
+    }
     const float pu = pos_modf(uv[0] + (uv[2] - uv[0]) * l1 + (uv[4] - uv[0]) * l2);
     const float pv = pos_modf(uv[1] + (uv[3] - uv[1]) * l1 + (uv[5] - uv[1]) * l2);
     const float lx = pu * (float)(w - 1u);
@@ -271,10 +280,15 @@ __device__ V3 shading_normal(const RtDevScene &S, const Shared &sh, V3 where, V3
             uint32_t h0, hs, he;
             float t, p1 = 0.f, p2 = 0.f;
             (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, l1, l2, h0, cn);
-            tri_test(S.triRec, tri, ray_o, mk(ray_d.x + tb.x, ray_d.y + tb.y, ray_d.z + tb.z), 0.f, RT_INF, t, p1, p2);
-            (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, p1, p2, hs, cn);
-            tri_test(S.triRec, tri, ray_o, mk(ray_d.x + lr.x, ray_d.y + lr.y, ray_d.z + lr.z), 0.f, RT_INF, t, p1, p2);
-            (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, p1, p2, he, cn);
+            if (bw == 1u && bh == 1u) { // one-texel height map: the neighbour samples are the same texel, wherever they land
+                (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, 0.f, 0.f, hs, cn);
+                (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, 0.f, 0.f, he, cn);
+            } else {
+                tri_test(S.triRec, tri, ray_o, mk(ray_d.x + tb.x, ray_d.y + tb.y, ray_d.z + tb.z), 0.f, RT_INF, t, p1, p2);
+                (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, p1, p2, hs, cn);
+                tri_test(S.triRec, tri, ray_o, mk(ray_d.x + lr.x, ray_d.y + lr.y, ray_d.z + lr.z), 0.f, RT_INF, t, p1, p2);
+                (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, p1, p2, he, cn);
+            }
             // xPart = (float)sin((hE-h0)*PI_F/2), etc. (:251-253) depend only on the two height bytes: host-libm tables
             const float xp = S.bumpSin[(he << 8) | h0];
             const float yp = S.bumpSin[(hs << 8) | h0];
