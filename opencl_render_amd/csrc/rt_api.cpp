@@ -561,7 +561,8 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
                 if (issue_chunk(G, on) != 0) return -1;
             }
             rounds = std::max<uint64_t>(rounds, G.rounds);
-            HIP_OK(stage(3, on, [&] { return rtw_launch_accum(&G.dev, &G.wf, base == 0 ? 1 : 0, on); }));
+            if (sampleCount > 1) // a one-sample frame's pixels were written by the kernels that finished them
+                HIP_OK(stage(3, on, [&] { return rtw_launch_accum(&G.dev, &G.wf, base == 0 ? 1 : 0, on); }));
         }
     }
     if (!serial)

@@ -25,6 +25,18 @@ enum { WS_RAY = 0, WS_SHADOW = 1 };
 __device__ __forceinline__ float4 pack4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 __device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
+// A frame with ONE sample per pixel needs no ordered accumulate (raytrace_opencl.c:726-741 adds to zeroed planes once): the
+// kernel that finishes a pixel writes its three u16 values itself, wf_accum_kernel is not launched.
+__device__ __forceinline__ void store_single_sample(const RtDevScene &S, uint32_t localPixel, V3 c)
+{
+    const uint32_t slot = localPixel / RT_TILE_PIXELS, inTile = localPixel % RT_TILE_PIXELS;
+    uint16_t *planes = S.tileBuf + (size_t)slot * 3 * RT_TILE_PIXELS + inTile;
+    const float scale = (float)(0xFFFF) / (float)S.sampleCount; // :728 (sampleCount is 1 here)
+    planes[0] = (uint16_t)sat_add_u16(0, c.x, scale);
+    planes[RT_TILE_PIXELS] = (uint16_t)sat_add_u16(0, c.y, scale);
+    planes[2 * RT_TILE_PIXELS] = (uint16_t)sat_add_u16(0, c.z, scale);
+}
+
 // Wave-aggregated queue append: one atomic per wave for all lanes that `want` a slot.  Must be reached by the lanes
 // together (it ballots over the lanes that execute it).
 __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
@@ -207,7 +219,10 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
         k = (float)gy + rand01(rng);
         dir.x += tb.x * k; dir.y += tb.y * k; dir.z += tb.z * k;
         hit_tri = camera_scan(S, localPixel, ld3(S.eye), dir, 0.f, RT_INF, RT_NONE, hit_t, hit_l1, hit_l2);
-        if (hit_tri == RT_NONE) W.sampleOut[outSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hit_tri == RT_NONE) {
+            if (S.sampleCount == 1u) store_single_sample(S, localPixel, mk(0.f, 0.f, 0.f));
+            else W.sampleOut[outSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const bool born = valid && hit_tri != RT_NONE;
     // workgroups are dealt to the shards round-robin: concurrently running groups append to different counters
@@ -537,7 +552,8 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             }
 
             if (finished) {
-                W.sampleOut[meta.x] = pack4(out, 0.f);
+                if (S.sampleCount == 1u) store_single_sample(S, meta.y, out);
+                else W.sampleOut[meta.x] = pack4(out, 0.f);
             } else {
                 // park the path in HBM until the grid has answered
                 if (rngDirty) W.rng[a] = rng;
