@@ -9,10 +9,12 @@
 //   wf_logic    one thread per waiting path: resumes the per-sample state machine of raytrace_opencl.c:532-724 where it
 //               stopped, runs it until the next grid ray (shadow ray :611, or a queued ray :530) and appends that ray
 //               to the next round's queue; paths with an empty ring retire their colour.
-//   wf_setup / wf_scatter   turn the round's requests into self-contained entries sorted by predicted walk length.
+//   wf_setup / wf_scatter   turn the round's requests into self-contained entries (DDA start state), cut long rays of a
+//               small round into exact segments, and order the entries of a big round by predicted walk length.
 //   wf_trace    one entry per lane: walks the non-uniform grid (:324-401) in blind phases, tests the occupied cells it
-//               passed wave-cooperatively.
-//   wf_accum    per pixel, samples in order: truncated saturating u16 accumulate into the tile buffer (:726-741).
+//               passed wave-cooperatively; a hit is published as (segment, pair) in hitKey and resolved by wf_logic.
+//   wf_accum    frames with several samples: per pixel, samples in order, truncated saturating u16 accumulate into the
+//               tile buffer (:726-741); a one-sample frame's pixels are written by wf_primary / wf_logic directly.
 //
 // Per path everything happens in the reference's order (RNG draws, ring FIFO, light loop), and paths never interact,
 // so the planes are bit-identical to the single-launch kernel (rt_kernels.hip) and to the oracle.
