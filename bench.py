@@ -207,6 +207,7 @@ def main():
         dist.all_reduce(t)
         total_stats = {k: int(v) for k, v in zip(keys, t.tolist())}
 
+    rehearsal_bad = 0
     if rank == 0:
         got = planes.cpu().numpy().view(np.uint16).reshape(3, H, W)
         ms_per_step = 1e3 * elapsed / args.steps
@@ -275,6 +276,7 @@ def main():
                 for c in range(3):
                     bad += int((want[c][y] != got[c, y]).sum())
             out["parity"] = {"rows_checked": len(rows), "mismatching_values": bad, "bar": "bit-exact u16 planes vs CPU oracle (rehearsal)"}
+            rehearsal_bad = bad
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O  # checker only: never part of the measured path
@@ -303,6 +305,8 @@ def main():
     rs.close()
     if world > 1:
         dist.destroy_process_group()
+    if rehearsal_bad:  # same rule as N=1: a frame that differs from the oracle voids the run (after the group is gone, so no rank hangs)
+        sys.exit(f"bench.py: rehearsal frame differs from the oracle in {rehearsal_bad} values")
 
 
 if __name__ == "__main__":

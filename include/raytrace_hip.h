@@ -267,6 +267,17 @@ int rtHipBuildSceneGridDevice(int device, cl_uint vertexCount, cl_uint triangleC
 
 void rtHipFree(void *p);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * TEST-ONLY: device-side known-answer runner (rt_kat.hip).  Runs the kernels' own building blocks -- the restatements
+ * of randF (raytrace_opencl.c:12-23), GetSpherePoint (:30-45), positive_modf (:25-28), RayIntersectsTriangle
+ * (:124-172, on the pre-resolved record), GetPointToLineSqLen (:83-101), GetBoxAddress (:174-193), BindInCube
+ * (:265-322) and the (float)pow(0.5f, x) of :631 -- over `count` items on a HIP device, one per thread; layouts per op
+ * are documented at the top of rt_kat.hip.  `table` is only read by RT_KAT_BOX (split planes, 3 x 257 floats, one
+ * array per axis).  Returns 0, -1 bad arguments, -2 no such device (there is no CPU stand-in), -3 HIP failure.
+ * ---------------------------------------------------------------------------------------------------------- */
+enum { RT_KAT_RANDF = 0, RT_KAT_SPHERE, RT_KAT_PMODF, RT_KAT_TRI, RT_KAT_PLINE, RT_KAT_BOX, RT_KAT_BIND, RT_KAT_POW, RT_KAT_OPS };
+int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint inStride, void *out, cl_uint outStride, const float *table);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,18 @@ int fail(const char *fmt, ...)
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));              \
     } while (0)
 
+// Device scratch of a scene build: freed when the scope ends, whichever way it ends.
+struct DevScratch {
+    std::vector<void *> blocks;
+    ~DevScratch() { for (void *p : blocks) (void)hipFree(p); }
+    hipError_t get(void **out, size_t bytes)
+    {
+        const hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+        if (e == hipSuccess) blocks.push_back(*out);
+        return e;
+    }
+};
+
 } // namespace
 
 struct rtHipScene {
@@ -82,6 +94,7 @@ struct rtHipScene {
         hipEvent_t done = nullptr;
         uint32_t logicBlocks = 1, traceBlocks = 1, queueBlocks = 1;
         uint32_t *hostCount = nullptr;  // pinned: queue length read back between round chunks
+        uint32_t *hostStatus = nullptr; // pinned + mapped: RT_WF_STATUS_* words the kernels write (rt_device.h)
         uint32_t rounds = 0;
     };
     std::vector<Group> groups;
@@ -218,8 +231,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 if ((uint32_t)d->triIndex[t].s[k] >= d->vertexCount) return fail("triangle %u references vertex %d of %u", t, d->triIndex[t].s[k], d->vertexCount);
         void *dv = nullptr, *di = nullptr, *dm = nullptr, *du = nullptr, *dn = nullptr;
         const uint64_t T = d->triangleCount ? d->triangleCount : 1, V = d->vertexCount ? d->vertexCount : 1;
-        HIP_OK(hipMalloc(&dv, V * 16)); HIP_OK(hipMalloc(&di, T * 16)); HIP_OK(hipMalloc(&dm, T * 4));
-        HIP_OK(hipMalloc(&du, T * 24)); HIP_OK(hipMalloc(&dn, T * 48));
+        DevScratch scratch; // the ABI arrays on the device, dropped once they are reshaped
+        HIP_OK(scratch.get(&dv, V * 16)); HIP_OK(scratch.get(&di, T * 16)); HIP_OK(scratch.get(&dm, T * 4));
+        HIP_OK(scratch.get(&du, T * 24)); HIP_OK(scratch.get(&dn, T * 48));
         if (d->vertexCount) HIP_OK(hipMemcpyAsync(dv, d->vertex, (uint64_t)d->vertexCount * 16, hipMemcpyHostToDevice, sc->stream));
         if (d->triangleCount) {
             HIP_OK(hipMemcpyAsync(di, d->triIndex, (uint64_t)d->triangleCount * 16, hipMemcpyHostToDevice, sc->stream));
@@ -231,7 +245,6 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         if (sc->alloc<float>(T * 16, &rec) || sc->alloc<float>(T * 24, &shade)) return -1;
         HIP_OK(rtk_launch_prepare(d->triangleCount, dv, di, dm, du, dn, rec, shade, sc->stream));
         HIP_OK(hipStreamSynchronize(sc->stream));
-        HIP_OK(hipFree(dv)); HIP_OK(hipFree(di)); HIP_OK(hipFree(dm)); HIP_OK(hipFree(du)); HIP_OK(hipFree(dn));
         D.triRec = rec; D.triShade = shade;
         for (uint32_t t = 0; t < d->triangleCount; ++t)
             if (d->triMaterial[t] >= (cl_int)d->materialCount) return fail("triangle %u uses material %d of %u", t, d->triMaterial[t], d->materialCount);
@@ -309,13 +322,13 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             if (sc->upload(range.data(), range.size(), &D.cellRange, "cellRange")) return -1;
             D.cellCount = (uint32_t)range.size();
             uint32_t *dPairTri = nullptr;
-            HIP_OK(hipMalloc((void **)&dPairTri, (size_t)(listSize ? listSize : 1) * 4));
+            DevScratch scratch;
+            HIP_OK(scratch.get((void **)&dPairTri, (size_t)listSize * 4));
             if (listSize) HIP_OK(hipMemcpyAsync(dPairTri, pairTri.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
             float *pairRec = nullptr;
             if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
             HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, dPairTri, D.triRec, pairRec, sc->stream));
             HIP_OK(hipStreamSynchronize(sc->stream));
-            HIP_OK(hipFree(dPairTri));
             D.pairRec = pairRec;
             HIP_OK(hipStreamSynchronize(sc->stream));
         }
@@ -406,6 +419,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         uint64_t sb = budget / (perPath * (pix ? pix : 1));
         if (sb < 1) sb = 1;
         if (sb > d->sampleCount) sb = d->sampleCount;
+        if (sb > 65535) sb = 65535; // the primary kernel's gridDim.y
         sc->samplesPerBatch = (uint32_t)sb;
         uint32_t groupCount = 1; // RT_WF_GROUPS: concurrent tile groups per instance (measured: no gain once rays are cut into segments)
         if (const char *b = getenv("RT_WF_GROUPS")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) groupCount = (uint32_t)v; }
@@ -426,6 +440,8 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         };
         parse_list(getenv("RT_WF_SEG"), segLen, 4);
         parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
+        uint32_t spinLimit = 16384u; // a ray makes at most 766 cell visits = 96 walk phases; RT_WF_SPIN_LIMIT lowers the guard to test its error path
+        if (const char *b = getenv("RT_WF_SPIN_LIMIT")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) spinLimit = (uint32_t)v; }
         uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
         if (const char *b = getenv("RT_WF_APPEND_RAYS")) appendRays = (uint32_t)strtoul(b, nullptr, 10);
         HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
@@ -475,6 +491,10 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, 2 * sizeof(uint32_t), sc->stream));
             HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
             HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void **)&G.hostStatus, sizeof(uint32_t) * RT_WF_STATUS_WORDS, hipHostMallocMapped));
+            memset(G.hostStatus, 0, sizeof(uint32_t) * RT_WF_STATUS_WORDS);
+            HIP_OK(hipHostGetDevicePointer((void **)&Wf.hostStatus, G.hostStatus, 0));
+            Wf.spinLimit = spinLimit;
             // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
             G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // setup / scatter: two generations of 8 resident workgroups per CU
             G.traceBlocks = (uint32_t)(ecap / 256); // trace: one workgroup per 256 sorted entries, dispatched in order; surplus groups exit at once
@@ -554,6 +574,11 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
             const hipStream_t on = streamOf(g);
             for (;;) {
                 HIP_OK(hipStreamSynchronize(on));
+                if (const uint32_t err = G.hostStatus[RT_WF_STATUS_ERROR]) {
+                    G.hostStatus[RT_WF_STATUS_ERROR] = 0u;
+                    return fail("wavefront pipeline: device error 0x%x%s -- the frame is invalid", err,
+                                (err & RT_WF_ERR_SPIN) ? " (wf_trace_kernel's walk guard tripped: rays were abandoned)" : "");
+                }
                 uint64_t waiting = 0;
                 for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += G.hostCount[i];
                 if (waiting == 0) break;
@@ -613,6 +638,7 @@ void rtHipSceneDestroy(rtHipScene *sc)
     for (auto &e : sc->stageEvents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &G : sc->groups) {
         if (G.hostCount) (void)hipHostFree(G.hostCount);
+        if (G.hostStatus) (void)hipHostFree(G.hostStatus);
         if (G.stream) { (void)hipStreamSynchronize(G.stream); (void)hipStreamDestroy(G.stream); }
         if (G.done) (void)hipEventDestroy(G.done);
     }

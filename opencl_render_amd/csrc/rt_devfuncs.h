@@ -327,6 +327,15 @@ __device__ __forceinline__ int sat_add_u16(int plane, float colour, float scale)
     return v;
 }
 
+// (float)pow(0.5f, x) with x = maxLen / halfAttenuationDistance (raytrace_opencl.c:631), NaN -> 1 (:632's isnan test):
+// 0.5^x = 2^-x in double on the device; exp2(-0) is exactly 1, skipped for the reference's own
+// scenes where halfAtt is infinite.
+__device__ __forceinline__ float half_falloff(float x)
+{
+    const float fall = (x == 0.f) ? 1.f : __double2float_rn(exp2(-(double)x));
+    return (fall == fall) ? fall : 1.f;
+}
+
 #define RT_MAX2(a, b) (((a) > (b)) ? (a) : (b)) /* raytrace.h:30 */
 
 } // namespace

@@ -88,11 +88,17 @@ struct RtDevScene {
 #define RT_WF_QSHARDS (2 * RT_WF_SHARDS) // queue slices: [0,SHARDS) main requests (one per waiting path), [SHARDS,2*SHARDS) look-ahead requests
 #define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input (wf_setup_kernel), 0 = longest
 #define RT_WF_SORT_COPIES 4   // independent histograms (workgroup % copies) to spread the atomics
+// host-visible status words of a tile group (RtWavefront::hostStatus)
+#define RT_WF_STATUS_ERROR 0  // RT_WF_ERR_* bits, sticky until the host clears them
+#define RT_WF_STATUS_WORDS 16
+#define RT_WF_ERR_SPIN 1u     // wf_trace_kernel's walk guard tripped: rays were abandoned, the frame is invalid
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
     uint32_t samplesInBatch;
     uint32_t lookAhead;      // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
+    uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (RT_WF_SPIN_LIMIT, default 16384)
+    uint32_t *hostStatus;    // pinned HOST words mapped into the device (RT_WF_STATUS_*): written by kernels, read by the host after a sync
     uint32_t segLen[4];      // aimed-at cell visits per segment for rounds with >= segRays[0] | >= segRays[1] | >= segRays[2] | fewer rays
     uint32_t segRays[3];     // (RT_WF_SEG="a,b,c,d", RT_WF_SEG_RAYS="a,b,c"; defaults 4096,256,64,16 and 700000,300000,30000)
     // per-path state, indexed by path id
@@ -109,7 +115,7 @@ struct RtWavefront {
     float4 *shP;             // P.xyz = (1-out)*weight*(1-transparency)*texture, the factors of :649-651 in the reference's order; w: N.L of this light
     float4 *shFace;          // xyz: the face[] entry that :647 will select (the other one is dead); w: 1 if front facing
     float4 *shAtt;           // shadow attenuation so far (only once a transparent occluder was met, :616-625)
-    float4 *shN, *shWhere;   // lightCount > 1 only: shading normal and hit point for the next light's set-up
+    float4 *shN;             // lightCount > 1 only: shading normal for the next light's set-up (the hit point rides in the request)
     // ray requests / results.  Queue slice s holds entries [s*shardCap, s*shardCap + counts[s]); a path born into shard s appends
     // its main requests to slice s and its look-ahead requests to slice RT_WF_SHARDS+s, so appends hit 512 different counters (a
     // single address sustains only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shard.

@@ -141,9 +141,7 @@ __device__ V3 trace_sample(const RtDevScene &S, const Shared &sh, uint32_t pixel
                     const float ndl = dot3(n, toL);
                     const float mag = __builtin_fabsf(ndl);
                     const float x = lmax / S.lightHalfAtt[j];
-                    // (float)pow(0.5f, x) in double: 0.5^x = 2^-x
-                    const float fall = __double2float_rn(exp2(-(double)x));
-                    const float e = mag * (fall == fall ? fall : 1.f);
+                    const float e = mag * half_falloff(x);
                     const float *lc = S.lightCol + 4 * j;
                     if (0.f <= ndl) {
                         face1.x += (1.f - face1.x) * atten.x * e * lc[0];

@@ -504,8 +504,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 } else if (pc == PC_LIGHT_ACCUM) { // :628-636
                     const float mag = __builtin_fabsf(ndl);
                     const float x = lmax / S.lightHalfAtt[j];
-                    const float fall = (x == 0.f) ? 1.f : __double2float_rn(exp2(-(double)x)); // exp2(-0) is exactly 1
-                    const float e = mag * (fall == fall ? fall : 1.f);
+                    const float e = mag * half_falloff(x);
                     const float *lc = S.lightCol + 4 * j;
                     if ((0.f <= ndl) == front) { // face[1] collects the lights in front of the normal, face[0] the others (:632-635)
                         face.x += (1.f - face.x) * atten.x * e * lc[0];
@@ -646,7 +645,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
-    __shared__ uint32_t extraWave[4], extraBase, raysWave[4], longWave[4], actWave[4], actBase;
+    __shared__ uint32_t extraWave[4], extraBase, extraVoidAt, extraVoidEnd, raysWave[4], longWave[4], actWave[4], actBase;
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     { // rays of the whole round and the longest queue slice: RT_WF_QSHARDS queue lengths, two per thread
@@ -756,14 +755,26 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         __syncthreads();
         const uint32_t sum = extraWave[0] + extraWave[1] + extraWave[2] + extraWave[3];
         if (threadIdx.x == 0) {
+            // A reservation is never undone (an add followed by a subtract is not atomic across workgroups: a later, smaller
+            // reservation could land inside the range the subtract gives back).  A count past extraCap just means "region B is
+            // full"; every reader clamps it.  The one workgroup whose range straddles the end owns [at, extraCap) and marks
+            // those slots empty; workgroups after it start past the end and own nothing.
             uint32_t at = sum ? atomicAdd(&W.sortExtra[0], sum) : 0u;
-            if (at + sum > W.extraCap) { if (sum) atomicSub(&W.sortExtra[0], sum); at = 0xffffffffu; }
+            extraVoidAt = 0u; extraVoidEnd = 0u;
+            if (sum && (uint64_t)at + sum > (uint64_t)W.extraCap) {
+                if (at < W.extraCap) { extraVoidAt = at; extraVoidEnd = W.extraCap; }
+                at = 0xffffffffu;
+            }
             extraBase = at;
         }
         __syncthreads();
         uint32_t before = incl - mineExtra;
         for (uint32_t w = 0; w < wave; ++w) before += extraWave[w];
-        if (extraBase == 0xffffffffu) { if (nseg > 1) nseg = 1; }
+        if (extraBase == 0xffffffffu) { // no room: this workgroup's rays stay whole
+            uint4 *ent = append ? W.sortedEnt : W.stageEnt;
+            for (uint32_t i = extraVoidAt + threadIdx.x; i < extraVoidEnd; i += 256) ent[4 * (size_t)(2u * W.capacity + i)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            if (nseg > 1) nseg = 1;
+        }
         else extraAt = 2u * W.capacity + extraBase + before; // region B of the entry arrays starts after the 2*capacity queue slots
     }
     uint32_t appendAt = 0; // append mode: where segment 0 of this lane's ray goes
@@ -878,7 +889,7 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
     __syncthreads();
     const uint32_t usedBlocks = (max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3])) + 255u) >> 8;
     const uint32_t itemsA = RT_WF_QSHARDS * usedBlocks;
-    const uint32_t extra = W.sortExtra[0];
+    const uint32_t extra = min(W.sortExtra[0], W.extraCap); // the count runs past the capacity when region B filled up (wf_setup_kernel)
     const uint32_t itemsB = (extra + 255u) >> 8;
     for (uint32_t item = blockIdx.x; item < itemsA + itemsB; item += gridDim.x) {
         uint32_t mine = 0;
@@ -918,7 +929,6 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 //     block table (two instructions instead of six: rt_device.h, gridBlockSparse), its bit with one multiply (bit-gather) and one bit-field extract;
 //   * an occupied cell is recorded as its packed coordinates only; the dense cell id (rank + popcount) is worked out in the
 //     test phase, where all 64 lanes have an item, instead of in the walk, where 6 of 64 lanes are on an occupied cell.
-#define RT_WF_SPIN_LIMIT 16384u
 #ifndef RT_WF_LEAN_WAVES
 #define RT_WF_LEAN_WAVES 4
 #endif
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // entries [0, total) and -- in an appended round -- the extra segments in region B, which follow in 64-entry chunks
     const uint32_t total = W.sortTotal[0];
     const bool appended = W.sortTotal[1] != 0u;
-    const uint32_t extra = appended ? W.sortExtra[0] : 0u;
+    const uint32_t extra = appended ? min(W.sortExtra[0], W.extraCap) : 0u;
     const uint32_t chunksA = (total + 63u) >> 6, chunksB = (extra + 63u) >> 6;
     if (blockIdx.x * 4 >= chunksA + chunksB) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
             if (walkers == 0ull) break;
             const int stalled = __popcll(__ballot(!walkEnded && !canWalk));
             if (stalled * RT_WF_LEAN_STALL > __popcll(walkers)) break;
-            if (++spins > RT_WF_SPIN_LIMIT) break; // cannot happen (a ray makes at most 766 visits); keeps a logic error from hanging the GPU
+            if (++spins > W.spinLimit) break; // cannot happen (a ray makes at most 766 visits); keeps a logic error from hanging the GPU
 #ifdef RT_DIAG_STAMPS
             dgWalkIters++;
 #endif
@@ -1153,9 +1163,12 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         dgTest += diag_stamp() - dgT0;
 #endif
         if (active && walkEnded) active = false; // walked to the end without a hit: hitKey[q] stays as it is
-        if (spins > RT_WF_SPIN_LIMIT || __ballot(active) == 0ull) break;
+        if (spins > W.spinLimit || __ballot(active) == 0ull) break;
     }
-    if (spins > RT_WF_SPIN_LIMIT) break; // logic error guard tripped: leave
+    if (spins > W.spinLimit) { // the guard tripped: rays of this wave were abandoned -- tell the host, which fails the frame
+        if (lane == 0) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_SPIN);
+        break;
+    }
 #ifdef RT_DIAG_STAMPS
     if (lane == 0) { // cycle anatomy of this wave (scripts/diag_stamps.py)
         atomicAdd(&S.stats[0], diag_stamp() - dgStart); atomicAdd(&S.stats[1], dgWalk); atomicAdd(&S.stats[2], dgTest);

@@ -66,6 +66,7 @@ RESIDENT_SYMBOLS = [
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
+    "rtHipDeviceKat",
 ]
 
 _lib = None
@@ -139,6 +140,7 @@ def lib() -> C.CDLL:
     L.rtHipBuildSceneGridDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
     L.rtHipBuildCameraListDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, vp, f32, u32, u32, vp, vp,
                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.rtHipDeviceKat.argtypes = [C.c_int, C.c_int, u32, vp, u32, vp, u32, vp]
     L.rtHipFree.argtypes = [vp]
     L.rtHipFree.restype = None
     _lib = L

@@ -121,21 +121,34 @@ def make_kat(path):
         ok = ref.BindInCube(C.byref(p), f3(bd[i]), f3(sc.box_min[0]), f3(sc.box_min[256]))
         bres[i] = ok, p.s[0], p.s[1], p.s[2]
     kat.update(bind_o=bo, bind_d=bd, bind_res=bres)
+    # pow(0.5f, maxLen/halfAtt) cast to float (:631).  Not a reference symbol: the call goes to the C library, so the known
+    # answers are THIS container's glibc pow -- the library the reference's C path calls here (parity-unpinned by
+    # the reference itself).  x = the float quotient the kernel forms first.
+    libm = C.CDLL("libm.so.6")
+    libm.pow.restype = C.c_double
+    libm.pow.argtypes = [C.c_double, C.c_double]
+    px = np.concatenate([rng.uniform(0, 40, 600), rng.uniform(0, 1e-3, 100), [0.0, 1.0, 2.0, 126.0, 127.0, 149.0, 150.0, 200.0, np.inf]]).astype(np.float32)
+    pw = np.array([libm.pow(0.5, float(v)) for v in px], np.float64).astype(np.float32)
+    kat.update(pow_x=px, pow_out=pw)
     np.savez_compressed(path, **kat)
 
 
 def main():
     if not O.have_ref():
         sys.exit("oracle/_ref/libref_kernel.so missing: run `make -C oracle` where /root/reference exists")
+    only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write, "kat" for kat.npz; default = everything
     for f in scenarios.ALL:
+        if only and f.__name__ not in only:
+            continue
         sc = f()
         R.build_lists(sc)
         planes = O.ref_render(sc)
         path = os.path.join(HERE, f"scene_{sc.name}.npz")
         save_scene(sc, planes, path)
         print(f"{sc.name}: {os.path.getsize(path) / 1024:.0f} KiB, lit pixels {(planes[0] > 0).mean():.2f}")
-    make_kat(os.path.join(HERE, "kat.npz"))
-    print("kat.npz written")
+    if not only or "kat" in only:
+        make_kat(os.path.join(HERE, "kat.npz"))
+        print("kat.npz written")
 
 
 if __name__ == "__main__":

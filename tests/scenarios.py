@@ -52,9 +52,13 @@ def spot_finite_range():
 
 
 def no_material():
-    """materialId -1 everywhere (:231,:550): zero texture => black diffuse, no bounces; normals still computed."""
-    sc = S.make_soup(40, 40, 800, 0.1, seed=15, samples=1, name="no_material")
-    sc.tri_material[:] = -1
+    """materialId -1 (:231,:550: zero texture => black, no bounces, no bump) on half of the triangles, mixed with a lit
+    textured material on the others: black pixels where a -1 triangle is nearest, and -1 triangles still occlude
+    (shadow rays :612-626 treat them as opaque, bounce rays stop on them)."""
+    mats = [_lambert(color=_tex(21, 6, 60, 256), bump=_tex(22, 5))]
+    sc = S.make_soup(40, 40, 500, 0.3, seed=15, samples=2, materials=mats, random_uv=True, name="no_material")
+    rng = np.random.Generator(np.random.PCG64(15))
+    sc.tri_material[rng.random(sc.triangle_count) < 0.5] = -1
     return sc
 
 

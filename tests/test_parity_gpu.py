@@ -233,3 +233,96 @@ def test_dropin_all_gpus_mode_threads_and_tile_deal(monkeypatch):
     ok, r, g, b = R.raytrace_all(n + 1, sc)
     assert ok, R.last_error()
     assert_planes((r, g, b), O.oracle_render(sc, threads=os.cpu_count() or 1), "640x360 soup over 5 instances")
+
+
+@pytest.mark.parametrize("append_rays", ["4000000000", "0"])  # every round appended | every round counting-sorted
+def test_region_b_overflow_keeps_rays_whole(monkeypatch, append_rays):
+    """Every ray of a full-coverage 640x360 frame is cut into segments of ~8 cell visits: the extra segments of the first
+    rounds (several million) do not fit region B of the entry arrays (2 x capacity = 524 288 entries here), so hundreds of
+    workgroups find it full while others still fit.  A reservation that does not fit must leave its rays whole and must
+    not disturb anybody else's slots (the add is never undone, readers clamp the count, the straddling range is marked
+    empty: wf_setup_kernel)."""
+    monkeypatch.setenv("RT_WF_SEG", "8,8,8,8")
+    monkeypatch.setenv("RT_WF_SEG_RAYS", "1,1,1")
+    monkeypatch.setenv("RT_WF_APPEND_RAYS", append_rays)
+    sc = S.make_soup(640, 360, 40_000, 0.06, seed=31, samples=1)
+    R.build_lists(sc)
+    got = R.render_resident(sc, 0)
+    assert (got[0] > 0).mean() > 0.95  # nearly every pixel is a path
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    assert_planes(got, want, f"region B overflow, RT_WF_APPEND_RAYS={append_rays}")
+
+
+def test_walk_guard_fails_the_frame(monkeypatch):
+    """wf_trace_kernel's guard against a walk that never ends (RtWavefront::spinLimit) abandons rays when it trips; the
+    frame must then FAIL, not return planes with missing hits.  Forced here with a limit of one walk phase."""
+    monkeypatch.setenv("RT_WF_SPIN_LIMIT", "1")
+    sc, _ = load_golden_scene("sparse_many_samples")  # long empty walks
+    rs = R.ResidentScene(sc, 0)
+    try:
+        with pytest.raises(RuntimeError, match="walk guard"):
+            rs.render()
+            rs.sync()
+    finally:
+        rs.close()
+    monkeypatch.delenv("RT_WF_SPIN_LIMIT")
+    assert_planes(R.render_resident(sc, 0), load_golden_scene("sparse_many_samples")[1], "after the guard test")
+
+
+# ---- BASELINE.json configs at their full sizes -------------------------------------------------------------------------
+# Same seeded soups as bench.py's workloads (SURVEY 8d); the oracle (OpenMP, all cores) renders every `step`-th pixel row of
+# the frame and those rows must match bit for bit.  Whole frames would take the oracle minutes at these sizes.
+
+def _bench_scene(name):
+    import bench
+    return bench.make_scene(name, 1)
+
+
+def _assert_sampled_rows(sc, got, step, what):
+    threads = os.cpu_count() or 1
+    bad = 0
+    rows = range(0, sc.height, step)
+    for y in rows:
+        want = O.oracle_render(sc, threads=threads, first_pixel=y * sc.width, pixel_count=sc.width)
+        for g, w in zip(got, want):
+            bad += int((np.asarray(g).reshape(sc.height, sc.width)[y] != w[y]).sum())
+    assert bad == 0, f"{what}: {bad} values differ from the oracle on {len(rows)} sampled rows"
+    assert (np.asarray(got[0]) > 0).mean() > 0.05, f"{what}: frame is (nearly) black"
+
+
+def test_baseline_config1_restated_256x256_10k_whole_frame():
+    """BASELINE config 1 as restated by SURVEY 8d (the .c4d file is not in the checkout): 256x256, 10 k triangles, S=1,
+    through the drop-in ABI; the WHOLE frame against the oracle."""
+    sc = _bench_scene("smoke")
+    ok, r, g, b = R.raytrace_all(1, sc)
+    assert ok, R.last_error()
+    assert_planes((r, g, b), O.oracle_render(sc, threads=os.cpu_count() or 1), "256x256 / 10 k")
+
+
+def test_baseline_config3_1080p_1m_lambert():
+    """BASELINE config 3, the headline workload: 1920x1080, 1 M triangles, Lambert + one distant light; every 4th row."""
+    sc = _bench_scene("lambert_1m")
+    _assert_sampled_rows(sc, R.render_resident(sc, 0), 4, "1920x1080 / 1 M")
+
+
+def test_baseline_config4_4k_1m_as_8_way_tile_deal():
+    """BASELINE config 4: 3840x2160, 1 M triangles, the frame dealt over 8 ranks (128x128 tiles round-robin, each rank with its
+    own scene instance and only its slice of the camera lists), rendered here on one device rank after rank; the ranks'
+    tile buffers add up to the frame.  Every 8th row against the oracle."""
+    sc = _bench_scene("lambert_4k")
+    planes = [np.zeros(sc.pixels, np.uint16) for _ in range(3)]
+    for rank in range(8):
+        rs = R.ResidentScene(sc, 0, R.tiles_of_rank(sc.width, sc.height, rank, 8))
+        try:
+            rs.render()
+            rs.readback(planes)
+        finally:
+            rs.close()
+    _assert_sampled_rows(sc, planes, 8, "3840x2160 / 1 M as an 8-way tile deal")
+
+
+def test_baseline_config5_4k_10m():
+    """BASELINE config 5 on one GPU: 3840x2160, 10 M triangles, shadow + bounce rays through the wavefront pipeline; every
+    16th row against the oracle (0.06 M rays/s per core at this size)."""
+    sc = _bench_scene("lambert_10m_4k")
+    _assert_sampled_rows(sc, R.render_resident(sc, 0), 16, "3840x2160 / 10 M")
