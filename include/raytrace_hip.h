@@ -247,8 +247,9 @@ int rtHipBuildCameraList(cl_uint width, cl_uint height, const cl_float eye[4], c
                          cl_uint **outStart, cl_uint **outEnd, cl_uint **outList, uint64_t *outListSize);
 
 /* The same camera lists built on a HIP device (rt_build_device.hip): identical membership (the arithmetic is one shared
- * header compiled for both), every pixel's entries ascending; the reference's neighbour de-duplication (:580-613, storage
- * sharing only) is not applied, so Start/End never alias.  Fails (no CPU fallback) when the device is missing.
+ * header compiled for both), every pixel's entries ascending, and the reference's neighbour de-duplication (:580-613: equal
+ * neighbouring lists share storage) applied, so Start, End and the list equal rtHipBuildCameraList's.  Fails (no CPU
+ * fallback) when the device is missing.
  * *deviceMs (optional) = device time of the build without the transfers. */
 int rtHipBuildCameraListDevice(int device, cl_uint width, cl_uint height, const cl_float eye[4], const cl_float eyeToTopLeft[4],
                                const cl_float leftToRight[4], const cl_float topToBottom[4], cl_float pixelSizeInv,

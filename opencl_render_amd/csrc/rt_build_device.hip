@@ -11,8 +11,8 @@
 //                    RT_BIG_RECT pixels are put on a list instead ...
 //   cam_rasterize_big ... and rasterized by one workgroup each, the pixels of the rectangle dealt to its threads
 //   cam_sort_pixels  one thread per pixel: insertion sort of its (short) list
-// The reference's neighbour de-duplication (:580-613: a pixel whose list equals its left or upper neighbour's shares the
-// storage) only changes where the entries live, not what a pixel's list holds; it is not done here, so Start/End never alias.
+//   cam_dedup_*      the reference's neighbour de-duplication (:580-613: a pixel whose list equals its left, else its upper
+//                    neighbour's shares that neighbour's storage), so Start/End/list equal the host builder's arrays
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -107,8 +107,60 @@ __global__ __launch_bounds__(256) void cam_sort_pixels(uint64_t P, const uint32_
     }
 }
 
+// ---- neighbour de-duplication (trianglelist.cpp:580-613) ---------------------------------------------------------------------
+// The reference scans the pixels in order; a pixel whose list equals that of its left neighbour -- else of the neighbour above
+// -- takes over that neighbour's (final) range, and the storage of the remaining lists is closed up.  Equality is a property of
+// the lists' contents, so which pixels alias which does not depend on the scan: mark every pixel's parent (left, up or
+// itself), compact the lists of the roots with an exclusive scan of their sizes, and resolve every pixel to the root of its
+// chain by pointer jumping (chains are at most W + H long: ceil(log2(W + H)) rounds).
+__global__ __launch_bounds__(256) void cam_dedup_mark(uint32_t W, uint64_t P, const uint32_t *__restrict__ start, const uint32_t *__restrict__ count,
+                                                      const uint32_t *__restrict__ list, uint32_t *__restrict__ parent, uint32_t *__restrict__ keep)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t x = (uint32_t)(p % W), n = count[p];
+    const uint32_t *mine = list + start[p];
+    auto same = [&](uint64_t q) {
+        if (count[q] != n) return false;
+        const uint32_t *other = list + start[q];
+        for (uint32_t i = 0; i < n; ++i)
+            if (mine[i] != other[i]) return false;
+        return true;
+    };
+    uint32_t par = (uint32_t)p;
+    if (x > 0 && same(p - 1)) par = (uint32_t)(p - 1);
+    else if (p >= W && same(p - W)) par = (uint32_t)(p - W);
+    parent[p] = par;
+    keep[p] = (par == (uint32_t)p) ? n : 0u;
+}
+
+__global__ __launch_bounds__(256) void cam_dedup_jump(uint64_t P, uint32_t *parent)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t a = parent[p];
+    parent[p] = parent[a]; // in place: whatever value is read is an ancestor, so every round at least halves the distance to the root
+}
+
+__global__ __launch_bounds__(256) void cam_dedup_compact(uint64_t P, const uint32_t *__restrict__ start, const uint32_t *__restrict__ count,
+                                                         const uint32_t *__restrict__ list, const uint32_t *__restrict__ parent,
+                                                         const uint32_t *__restrict__ newStart, uint32_t *__restrict__ outStart,
+                                                         uint32_t *__restrict__ outEnd, uint32_t *__restrict__ outList)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t root = parent[p];
+    const uint32_t at = newStart[root], n = count[root];
+    outStart[p] = at;
+    outEnd[p] = at + n;
+    if (root == (uint32_t)p) {
+        const uint32_t *src = list + start[p];
+        for (uint32_t i = 0; i < n; ++i) outList[at + i] = src[i];
+    }
+}
+
 struct Buffers { // frees what it holds
-    void *p[10] = { nullptr };
+    void *p[16] = { nullptr };
     int n = 0;
     template <class T> hipError_t alloc(T **dst, size_t count)
     {
@@ -174,7 +226,16 @@ extern "C" int rtHipBuildCameraListDevice(int device, cl_uint W, cl_uint H, cons
         hipLaunchKernelGGL(cam_rasterize<true>, dim3(tBlocks), dim3(256), 0, nullptr, W, H, T, dPos, dCount, dStart, dList, dBigList, dBigCount);
         hipLaunchKernelGGL(cam_rasterize_big<true>, dim3(bigBlocks), dim3(256), 0, nullptr, W, H, dPos, dCount, dStart, dList, dBigList, dBigCount);
     }
-    hipLaunchKernelGGL(cam_sort_pixels, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, nullptr, P, dStart, dCount, dList, dEnd);
+    const uint32_t pBlocks = (uint32_t)((P + 255) / 256);
+    hipLaunchKernelGGL(cam_sort_pixels, dim3(pBlocks), dim3(256), 0, nullptr, P, dStart, dCount, dList, dEnd);
+    // neighbour de-duplication: parents, sizes kept, new starts of the roots, roots of everybody, compacted storage
+    uint32_t *dParent = nullptr, *dKeep = nullptr, *dNewStart = nullptr, *dOutList = nullptr, *dOutStart = nullptr;
+    BUILD_OK(buf.alloc(&dParent, P)); BUILD_OK(buf.alloc(&dKeep, P)); BUILD_OK(buf.alloc(&dNewStart, P)); BUILD_OK(buf.alloc(&dOutList, total));
+    BUILD_OK(buf.alloc(&dOutStart, P));
+    hipLaunchKernelGGL(cam_dedup_mark, dim3(pBlocks), dim3(256), 0, nullptr, W, P, dStart, dCount, dList, dParent, dKeep);
+    BUILD_OK(hipcub::DeviceScan::ExclusiveSum(tmp, tmpBytes, dKeep, dNewStart, (int)P, nullptr));
+    for (uint64_t reach = 1; reach < (uint64_t)W + H; reach *= 2) hipLaunchKernelGGL(cam_dedup_jump, dim3(pBlocks), dim3(256), 0, nullptr, P, dParent);
+    hipLaunchKernelGGL(cam_dedup_compact, dim3(pBlocks), dim3(256), 0, nullptr, P, dStart, dCount, dList, dParent, dNewStart, dOutStart, dEnd, dOutList);
     BUILD_OK(hipGetLastError());
     BUILD_OK(hipEventRecord(e1, nullptr));
     BUILD_OK(hipEventSynchronize(e1));
@@ -183,15 +244,19 @@ extern "C" int rtHipBuildCameraListDevice(int device, cl_uint W, cl_uint H, cons
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (deviceMs) *deviceMs = ms;
 
+    uint32_t lastNew = 0, lastKeep = 0;
+    BUILD_OK(hipMemcpy(&lastNew, dNewStart + (P - 1), 4, hipMemcpyDeviceToHost));
+    BUILD_OK(hipMemcpy(&lastKeep, dKeep + (P - 1), 4, hipMemcpyDeviceToHost));
+    const uint64_t kept = (uint64_t)lastNew + lastKeep; // entries left after the de-duplication
     cl_uint *start = (cl_uint *)std::malloc((size_t)P * 4), *end = (cl_uint *)std::malloc((size_t)P * 4);
-    cl_uint *list = (cl_uint *)std::malloc((size_t)(total ? total : 1) * 4);
+    cl_uint *list = (cl_uint *)std::malloc((size_t)(kept ? kept : 1) * 4);
     if (!start || !end || !list) { std::free(start); std::free(end); std::free(list); return -2; }
-    if (hipMemcpy(start, dStart, (size_t)P * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(end, dEnd, (size_t)P * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        (total && hipMemcpy(list, dList, (size_t)total * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+    if (hipMemcpy(start, dOutStart, (size_t)P * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(end, dEnd, (size_t)P * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (kept && hipMemcpy(list, dOutList, (size_t)kept * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
         std::free(start); std::free(end); std::free(list);
         return -4;
     }
-    *outStart = start; *outEnd = end; *outList = list; *outListSize = total;
+    *outStart = start; *outEnd = end; *outList = list; *outListSize = kept;
     return 0;
 }
 

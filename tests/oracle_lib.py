@@ -78,6 +78,13 @@ def oracle() -> C.CDLL:
         L.rt_oracle_grid_trace.restype = C.c_uint32
         L.rt_oracle_grid_trace.argtypes = [C.POINTER(OracleScene), fp, fp, C.c_float, C.c_float, C.c_uint32, fp, fp, fp]
         L.rt_oracle_texel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, fp, C.c_float, C.c_float, fp]
+        vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
+        L.rt_oracle_build_camera_list.argtypes = [u32, u32, fp, fp, fp, fp, f32, u32, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.rt_oracle_build_scene_grid.argtypes = [u32, u32, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.rt_oracle_camera_position.argtypes = [fp, fp, fp, fp, f32, fp, fp]
+        L.rt_oracle_box_meets_triangle.argtypes = [fp, fp, fp, fp, fp]
+        L.rt_oracle_builders_free.argtypes = [vp]
+        L.rt_oracle_builders_free.restype = None
         _oracle = L
     return _oracle
 
@@ -160,3 +167,37 @@ def ref_render(sc, first_pixel: int = 0, pixel_count: int = None):
                      sc.light_count, _ptr(sc.light_type), _ptr(sc.light_pos), _ptr(sc.light_dir), _ptr(sc.light_col),
                      _ptr(sc.light_radius), _ptr(sc.light_half_att), _ptr(planes[0]), _ptr(planes[1]), _ptr(planes[2]), first_pixel, n)
     return [p.reshape(sc.height, sc.width) for p in planes]
+
+
+# ---- builders (oracle/rt_oracle_builders.c: independent serial restatement of trianglelist.cpp; parity unpinned) ----------
+
+def _take_oracle(ptr, count, dtype):
+    out = np.empty(int(count), dtype)
+    if count:
+        C.memmove(out.ctypes.data, ptr.value, int(count) * out.itemsize)
+    oracle().rt_oracle_builders_free(ptr)
+    return out
+
+
+def _f3p(a):
+    return np.ascontiguousarray(a[:3], np.float32).ctypes.data_as(C.POINTER(C.c_float))
+
+
+def oracle_camera_list(sc):
+    """(start[P], end[P], list[n]) as CameraTriangleList::New would build them (trianglelist.cpp:520-626)."""
+    ps, pe, pl, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = oracle().rt_oracle_build_camera_list(sc.width, sc.height, _f3p(sc.eye), _f3p(sc.eye_to_top_left), _f3p(sc.left_to_right),
+                                              _f3p(sc.top_to_bottom), sc.pixel_size_inv, sc.triangle_count, _ptr(sc.vertex),
+                                              _ptr(sc.tri_index), C.byref(ps), C.byref(pe), C.byref(pl), C.byref(n))
+    assert rc == 0
+    return _take_oracle(ps, sc.pixels, np.uint32), _take_oracle(pe, sc.pixels, np.uint32), _take_oracle(pl, n.value, np.uint32)
+
+
+def oracle_scene_grid(sc):
+    """(box_min[257,4], start[256^3+1], list[n]) as SceneTriangleList::New would build them (trianglelist.cpp:655-737)."""
+    box = np.zeros((257, 4), np.float32)
+    ps, pl, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = oracle().rt_oracle_build_scene_grid(sc.vertex_count, sc.triangle_count, _ptr(sc.vertex), _ptr(sc.tri_index), _ptr(box),
+                                             C.byref(ps), C.byref(pl), C.byref(n))
+    assert rc == 0
+    return box, _take_oracle(ps, 256 ** 3 + 1, np.uint32), _take_oracle(pl, n.value, np.uint32)

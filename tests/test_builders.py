@@ -92,3 +92,66 @@ def test_empty_scene_builds():
     sc = S.make_soup(16, 16, 1, 0.1, seed=3)
     R.build_lists(sc)
     assert len(sc.grid_list) >= 1
+
+
+# ---- against the INDEPENDENT builder oracle (oracle/rt_oracle_builders.c) -----------------------------------------------------
+# That file restates trianglelist.cpp serially in its own code (keys + sort, like the reference) and shares nothing with
+# rt_build_shared.h.  Still "parity unpinned" against the reference itself (trianglelist.cpp cannot be compiled here), but no
+# longer a comparison of the product with its own twin.
+
+def _builder_cases():
+    rng = np.random.Generator(np.random.PCG64(4))
+    cases = [
+        S.make_soup(72, 56, 1200, 0.12, seed=77),
+        S.make_soup(200, 150, 2500, 0.08, seed=20),                     # several tiles, ragged edges
+        S.make_soup(64, 48, 300, 1.4, seed=8),                          # triangles larger than the image, many off-screen vertices
+        S.make_soup(97, 61, 900, 0.3, seed=9, depth=(0.2, 6.0)),        # near triangles: huge projections, some straddle the image border
+    ]
+    deg = S.make_soup(56, 40, 900, 0.12, seed=18)                      # zero-area and axis-parallel triangles
+    v = deg.vertex.reshape(-1, 3, 4)
+    v[::7, 1] = v[::7, 0]; v[::7, 2] = v[::7, 0]
+    v[::11, 2] = v[::11, 1]
+    v[::5, 1, 1] = v[::5, 0, 1]                                         # horizontal edge ab (slope division by zero, :143-150)
+    v[::3, 2, 0] = v[::3, 1, 0]                                         # vertical edge bc
+    cases.append(deg)
+    snap = S.make_soup(80, 60, 600, 0.2, seed=10)                       # vertices exactly on pixel corners / split planes
+    snap.vertex[:, :3] = np.round(snap.vertex[:, :3] * 16) / 16 + np.float32(0)  # (+0 turns -0.0 into +0.0: where equal keys land is the sort's business, in the reference too)
+    cases.append(snap)
+    del rng
+    return cases
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_host_builders_equal_independent_oracle(idx):
+    sc = _builder_cases()[idx]
+    R.build_lists(sc, threads=4)
+    ostart, oend, olist = O.oracle_camera_list(sc)
+    assert np.array_equal(sc.cam_start, ostart), "camera Start (incl. the neighbour aliasing of :580-613)"
+    assert np.array_equal(sc.cam_end, oend), "camera End"
+    assert np.array_equal(sc.cam_list, olist), "camera list (membership, ascending order, de-duplicated storage)"
+    obox, ogstart, oglist = O.oracle_scene_grid(sc)
+    assert sc.box_min.tobytes() == obox.tobytes(), "split planes"
+    assert np.array_equal(sc.grid_start, ogstart), "grid Start"
+    assert np.array_equal(sc.grid_list, oglist), "grid list"
+
+
+def test_builder_oracle_function_level():
+    """Projection and box/triangle overlap, spot-checked against first principles (not against the product)."""
+    L = O.oracle()
+    fp = C.POINTER(C.c_float)
+    sc = S.make_soup(64, 48, 10, 0.1, seed=1)
+    # a point on the ray through pixel corner (x, y) projects to (x, y) (trianglelist.cpp:74-90)
+    for x, y, k in [(0, 0, 1.0), (10, 7, 2.5), (63.5, 47.25, 0.75)]:
+        v = (sc.eye[:3] + np.float32(k) * (sc.eye_to_top_left[:3] + sc.left_to_right[:3] * np.float32(x) + sc.top_to_bottom[:3] * np.float32(y))).astype(np.float32)
+        out = np.zeros(2, np.float32)
+        L.rt_oracle_camera_position(O._f3p(sc.eye), O._f3p(sc.eye_to_top_left), O._f3p(sc.left_to_right), O._f3p(sc.top_to_bottom),
+                                    sc.pixel_size_inv, np.ascontiguousarray(v).ctypes.data_as(fp), out.ctypes.data_as(fp))
+        assert np.allclose(out, (x, y), atol=1e-3)
+    f = lambda *a: np.array(a, np.float32).ctypes.data_as(fp)
+    lo, hi = np.array([0, 0, 0], np.float32), np.array([1, 1, 1], np.float32)
+    inside = L.rt_oracle_box_meets_triangle(lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), f(0.2, 0.2, 0.5), f(0.8, 0.2, 0.5), f(0.5, 0.8, 0.5))
+    through = L.rt_oracle_box_meets_triangle(lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), f(-5, -5, 0.5), f(5, -5, 0.5), f(0, 9, 0.5))
+    apart = L.rt_oracle_box_meets_triangle(lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), f(2, 2, 2), f(3, 2, 2), f(2, 3, 2))
+    corner = L.rt_oracle_box_meets_triangle(lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), f(1.4, -0.2, 0.5), f(1.4, 0.4, 0.5), f(0.8, -0.2, 0.5))
+    assert inside and through and not apart
+    assert corner  # its bounding box overlaps and the clipped polygon is not empty: a diagonal cut through the corner region

