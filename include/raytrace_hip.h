@@ -269,6 +269,77 @@ int rtHipBuildSceneGridDevice(int device, cl_uint vertexCount, cl_uint triangleC
 void rtHipFree(void *p);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * (3) HEADLESS FRONT-END and OUTPUT SINKS (rt_frontend.cpp; host code, no GPU involved).
+ * The SDK-free arithmetic of the reference's scene extraction (source/render.cpp) and of its output path, so that a
+ * host without Cinema 4D can feed RaytraceAll from plain meshes and get an image file back.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* SetCamera (render.cpp:461-491): camera vectors from eye position, look-at point, up vector, horizontal field of view
+ * (radians) and image size.  Same operations in the same order: the eye-to-top-left vector keeps the LENGTH of
+ * (object - position), pixel vectors are unit vectors divided by pixelSizeInv = width / (2 |object - position| tan(fov/2)). */
+void rtHipSetCamera(cl_float3 *outEyeToTopLeft, cl_float3 *outLeftToRight, cl_float3 *outTopToBottom, cl_float *outPixelSizeInv,
+                    const cl_float position[3], const cl_float object[3], const cl_float up[3], cl_float fov, cl_uint width, cl_uint height);
+
+/* One polygon object as AddPolygonsRecursive sees it (render.cpp:707-963), points already in world space. */
+typedef struct rtHipMesh {
+    cl_uint pointCount;
+    const cl_float3 *points;
+    cl_uint polygonCount;
+    const cl_int *polygons;           /* 4 indices a,b,c,d per polygon; c == d marks a triangle (render.cpp:736) */
+    const cl_float3 *cornerNormals;   /* optional, 4 per polygon (a,b,c,d), any length; NULL = face normal turned to the camera (:754-771) */
+    const cl_float2 *cornerUv;        /* optional, 4 per polygon; NULL = (0,0),(0,1),(1,1) for every triangle (:956-963) */
+    const cl_int *polygonMaterial;    /* optional, one id per polygon; NULL = -1, "no material" (:1098) */
+} rtHipMesh;
+
+/* Sizes of the arrays rtHipMeshFill writes: vertices = all points, triangles = 1 per triangle + 2 per quad.
+ * Returns 0, -1 null argument, -2 a polygon index outside its object's points, -3 too many elements. */
+int rtHipMeshCount(const rtHipMesh *meshes, cl_uint meshCount, cl_uint *vertexCount, cl_uint *triangleCount);
+
+/* Fills RaytraceAll's geometry arrays (vertex[V], triangleVertexIndex[T], triangleMaterialId[T], triangleUv[3T],
+ * triangleNormal[3T]) from the meshes: a quad becomes (a,b,c) and (a,c,d) with its corner normals and UVs following. */
+int rtHipMeshFill(const rtHipMesh *meshes, cl_uint meshCount, const cl_float cameraEye[3], cl_float3 *vertex, cl_int3 *triIndex,
+                  cl_int *triMaterial, cl_float2 *triUv, cl_float3 *triNormal);
+
+/* One light as render.cpp:965-993 stores it: direction normalised, colour x brightness, radius 0.52 (degrees; the sun's
+ * angular size, used for every light), half-attenuation distance infinite.  `type` as in raytrace_opencl.h:1-12. */
+void rtHipLightFill(cl_uint index, cl_int type, const cl_float position[3], const cl_float direction[3], const cl_float colour[3],
+                    cl_float brightness, cl_int *lightType, cl_float3 *lightPosition, cl_float3 *lightDirection, cl_float3 *lightColour,
+                    cl_float *lightRadius, cl_float *lightHalfAttenuationDistance);
+
+/* Material channels in the reference's order: colour, reflection, transparency, bump, luminance (render.cpp:1136). */
+typedef struct rtHipChannelSpec {
+    cl_int enabled;            /* the channel exists and is switched on (render.cpp:1143-1145) */
+    cl_uint width, height;     /* bitmap size; 0 = the channel has no bitmap */
+    const cl_uchar3 *pixels;   /* width*height texels, row-major, 4 bytes each */
+} rtHipChannelSpec;
+typedef struct rtHipMaterialSpec {
+    rtHipChannelSpec channel[5];
+    cl_float color[3];         /* MATERIAL_COLOR_COLOR, used when the colour channel has no bitmap (render.cpp:1254-1275) */
+    cl_float brightness;       /* MATERIAL_COLOR_BRIGHTNESS */
+} rtHipMaterialSpec;
+
+/* The channel table rules of render.cpp:1136-1309 for bitmaps and absent channels (C4D shaders need the SDK): a channel
+ * that is off is 0x0; reflection / transparency switched on without an image are 1x1 of 0.2 / 1.0; every non-colour
+ * channel still 0x0 becomes 1x1 black; a colour channel without an image becomes 1x1 of color x brightness;
+ * materialImageStart[5*count] receives the texel total.  Call with textures == NULL to size the atlas (*texturesSize),
+ * then again with a buffer.  Returns 0, -1 null argument, -2 capacity too small, -3 atlas larger than 2^31 texels. */
+int rtHipBakeMaterials(const rtHipMaterialSpec *materials, cl_uint materialCount, cl_uint2 *materialImageSize, cl_int *materialImageStart,
+                       cl_uchar3 *textures, cl_uint texturesCapacity, cl_uint *texturesSize);
+
+/* u16 planes -> interleaved 8-bit RGB, top row first: value / 256 (render.cpp:1379-1382).  lowByteCompat != 0 keeps the LOW
+ * byte instead, which is what the reference's debug BMP does (writebmp.cpp:136-141, a truncation bug). */
+void rtHipPlanesToRgb8(cl_uint width, cl_uint height, const cl_ushort *red, const cl_ushort *green, const cl_ushort *blue,
+                       cl_uchar *rgb, int lowByteCompat);
+
+/* writebmp3s (writebmp.cpp:124-177) to a path of the caller's choice: 54-byte header with file size 54 + 3wh, 24-bit BGR,
+ * bottom row first, rows padded to 4 bytes.  Returns 0, -1 bad argument, -3 image too large for the header, -4 I/O error. */
+int rtHipWriteBmp(const char *path, cl_uint width, cl_uint height, const cl_ushort *red, const cl_ushort *green, const cl_ushort *blue,
+                  int lowByteCompat);
+
+/* Binary PPM (P6, maxval 255) of the same 8-bit image, top row first. */
+int rtHipWritePpm(const char *path, cl_uint width, cl_uint height, const cl_ushort *red, const cl_ushort *green, const cl_ushort *blue);
+
+/* ------------------------------------------------------------------------------------------------------------
  * TEST-ONLY: device-side known-answer runner (rt_kat.hip).  Runs the kernels' own building blocks -- the restatements
  * of randF (raytrace_opencl.c:12-23), GetSpherePoint (:30-45), positive_modf (:25-28), RayIntersectsTriangle
  * (:124-172, on the pre-resolved record), GetPointToLineSqLen (:83-101), GetBoxAddress (:174-193), BindInCube

@@ -67,6 +67,7 @@ RESIDENT_SYMBOLS = [
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
     "rtHipDeviceKat",
+    "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
 ]
 
 _lib = None

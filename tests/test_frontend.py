@@ -1,0 +1,156 @@
+"""CPU tests of the headless front-end and the output sinks (rt_frontend.cpp; counterparts of render.cpp:461-491, 676-1003,
+1136-1309, 1372-1386 and writebmp.cpp:124-177).  The reference holds no fixtures for these and its callers need the Cinema 4D
+SDK, so the checks are: an independent numpy float32 restatement of SetCamera, structural properties of the mesh contract,
+the channel table written out by hand, and BMP/PPM bytes rebuilt independently in Python.  End to end: mesh -> host builders
+-> CPU ORACLE (checker only) -> image file."""
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import frontend_cases as FC
+from opencl_render_amd import frontend as F, raytrace as R
+
+f32 = np.float32
+
+
+def numpy_set_camera(pos, obj, up, fov, w, h):
+    """render.cpp:461-491 restated with numpy scalars (float32 arithmetic, double sqrt/tan rounded to float)."""
+    pos, obj, up = (np.asarray(v, f32) for v in (pos, obj, up))
+    cam = (obj - pos).astype(f32)
+    dot = lambda a, b: f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+    side = np.array([f32(f32(up[1] * cam[2]) - f32(up[2] * cam[1])), f32(f32(up[2] * cam[0]) - f32(up[0] * cam[2])),
+                     f32(f32(up[0] * cam[1]) - f32(up[1] * cam[0]))], f32)
+    mid_left = f32(f32(math.sqrt(float(dot(cam, cam)))) * f32(math.tan(float(f32(f32(fov) / f32(2))))))
+    mid_top = f32(f32(mid_left * f32(h)) / f32(w))
+    side_u = (side / f32(math.sqrt(float(dot(side, side))))).astype(f32)
+    up_u = (up / f32(math.sqrt(float(dot(up, up))))).astype(f32)
+    inv = f32(f32(w) / f32(f32(2) * mid_left))
+    tl = np.array([f32(f32(cam[i] - f32(mid_left * side_u[i])) + f32(mid_top * up_u[i])) for i in range(3)], f32)
+    return tl, (side_u / inv).astype(f32), (-up_u / inv).astype(f32), inv
+
+
+@pytest.mark.parametrize("pos,obj,up,fov,w,h", [
+    ((0, 0, 0), (0, 0, 1), (0, 1, 0), math.radians(90), 64, 48),
+    ((0.1, 1.3, -0.6), (0.0, 0.9, 2.5), (0, 1, 0), math.radians(60), 160, 120),
+    ((3, 2, 1), (-1, 0.5, 4), (0.1, 2.0, -0.3), 0.7, 1920, 1080),   # up neither unit nor orthogonal, |look| != 1
+])
+def test_set_camera_matches_numpy_restatement_and_geometry(pos, obj, up, fov, w, h):
+    tl, lr, tb, inv = F.set_camera(pos, obj, up, fov, w, h)
+    etl, elr, etb, einv = numpy_set_camera(pos, obj, up, fov, w, h)
+    assert tl[:3].tobytes() == etl.tobytes() and lr[:3].tobytes() == elr.tobytes() and tb[:3].tobytes() == etb.tobytes()
+    assert f32(inv).tobytes() == f32(einv).tobytes()
+    # geometry: the image centre looks at `obj` (the eye-to-top-left vector keeps |obj - pos|), pixel vectors have length 1/inv
+    centre = tl[:3] + lr[:3] * f32(w / 2) + tb[:3] * f32(h / 2)
+    look = np.asarray(obj, f32) - np.asarray(pos, f32)
+    assert np.allclose(centre, look, atol=2e-3 * np.linalg.norm(look))
+    assert np.isclose(np.linalg.norm(lr[:3]), 1 / inv, rtol=1e-5) and np.isclose(np.linalg.norm(tb[:3]), 1 / inv, rtol=1e-5)
+    # horizontal field of view: angle between the rays through the left and right edge at mid height
+    left = tl[:3] + tb[:3] * f32(h / 2)
+    right = left + lr[:3] * f32(w)
+    ang = math.acos(float(np.dot(left, right) / (np.linalg.norm(left) * np.linalg.norm(right))))
+    assert abs(ang - fov) < 1e-3
+
+
+def test_mesh_contract_quads_normals_uvs():
+    eye = np.array([0, 0, -5], f32)
+    pts = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [2, 0, 1]], f32)
+    pol = np.array([[0, 1, 2, 3], [1, 4, 2, 2]], np.int32)  # a quad and a triangle (c == d)
+    uv = np.arange(16, dtype=f32).reshape(2, 4, 2)
+    nrm = np.zeros((2, 4, 3), f32)
+    nrm[0] = [[0, 0, -2], [0, 3, -4], [1, 0, 0], [0, 0, -0.5]]
+    nrm[1] = [[1, 1, 1], [0, 1, 0], [0, 0, 9], [0, 0, 9]]
+    v, ti, tm, tuv, tn = F.mesh_arrays([F.Mesh(pts, pol, nrm, uv, np.array([5, -1], np.int32))], eye)
+    assert v.shape == (5, 4) and np.array_equal(v[:, :3], pts)
+    assert ti[:, :3].tolist() == [[0, 1, 2], [0, 2, 3], [1, 4, 2]]          # (a,b,c), (a,c,d), then the triangle
+    assert tm.tolist() == [5, 5, -1]
+    assert tuv.reshape(3, 3, 2).tolist() == [uv[0, [0, 1, 2]].tolist(), uv[0, [0, 2, 3]].tolist(), uv[1, [0, 1, 2]].tolist()]
+    want = lambda n: (np.asarray(n, np.float64) / np.linalg.norm(np.asarray(n, np.float64))).astype(f32)
+    got = tn.reshape(3, 3, 4)[:, :, :3]
+    for t, corners in enumerate([(0, [0, 1, 2]), (0, [0, 2, 3]), (1, [0, 1, 2])]):
+        for k, c in enumerate(corners[1]):
+            assert got[t, k].tobytes() == want(nrm[corners[0], c]).tobytes()
+    # without normals and UVs: camera-facing face normals (render.cpp:754-771) and the fallback triple (:956-963)
+    v, ti, tm, tuv, tn = F.mesh_arrays([F.Mesh(pts, pol)], eye)
+    assert tm.tolist() == [-1, -1, -1]
+    assert tuv.reshape(3, 3, 2).tolist() == [[[0, 0], [0, 1], [1, 1]]] * 3
+    n = tn.reshape(3, 3, 4)[:, :, :3]
+    assert (n[:, 0] == n[:, 1]).all() and (n[:, 1] == n[:, 2]).all()
+    for t in range(3):
+        a = v[ti[t, 0], :3]
+        assert np.dot(a - eye[:3], n[t, 0]) < 0 and abs(np.linalg.norm(n[t, 0]) - 1) < 1e-6  # turned towards the camera
+    # the same quad seen from behind flips the normal
+    _, _, _, _, tn2 = F.mesh_arrays([F.Mesh(pts, pol)], np.array([0, 0, 5], f32))
+    assert np.allclose(tn2.reshape(3, 3, 4)[0, 0, :3], -n[0, 0])
+    with pytest.raises(ValueError):
+        F.mesh_arrays([F.Mesh(pts, np.array([[0, 1, 9, 9]], np.int32))], eye)
+
+
+def test_material_channel_rules():
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    size, start, tex = F.bake_materials([
+        dict(),                                                    # nothing: colour 1x1 white, the others 1x1 black
+        dict(color=img, reflection=True, transparency=True, rgb=(0.2, 0.4, 0.6)),
+        dict(rgb=(0.5, 0.25, 1.0), brightness=0.5, bump=img[:1], luminance=False),
+    ])
+    assert size.tolist() == [[1, 1]] * 5 + [[3, 2], [1, 1], [1, 1], [1, 1], [1, 1]] + [[1, 1], [1, 1], [1, 1], [3, 1], [1, 1]]
+    # material 0: reflection, transparency, bump, luminance get a black texel each IN CHANNEL ORDER, the colour texel comes last
+    assert start[:5].tolist() == [4, 0, 1, 2, 3] and tex[:5, :3].tolist() == [[0, 0, 0]] * 4 + [[255, 255, 255]]
+    # material 1: the bitmap (6 texels), reflectance floor(0.5 + 0.2*255) = 51, transparency 255, black bump and luminance
+    assert start[5:10].tolist() == [5, 11, 12, 13, 14]
+    assert tex[5:11, :3].tolist() == img.reshape(-1, 3).tolist()
+    assert tex[11:15, :3].tolist() == [[51] * 3, [255] * 3, [0] * 3, [0] * 3]
+    # material 2: colour = rgb * brightness -> floor(0.5 + c*255)
+    assert start[10:16].tolist() == [21, 15, 16, 17, 20, 22]  # black reflection, transparency; 3 bump texels; black luminance; colour; total
+    assert tex[17:20, :3].tolist() == img[:1].reshape(-1, 3).tolist()
+    assert tex[21, :3].tolist() == [int(math.floor(0.5 + c * 255)) for c in (0.25, 0.125, 0.5)]
+    assert start[-1] == len(tex) == 22                             # the total goes last (render.cpp:1306)
+
+
+def python_bmp(rgb8):
+    """writebmp3s's layout (writebmp.cpp:124-177) rebuilt independently: 54-byte header, BGR, bottom-up, rows padded to 4."""
+    h, w, _ = rgb8.shape
+    head = b"BM" + struct.pack("<I", 54 + 3 * w * h) + b"\0\0\0\0" + struct.pack("<I", 54)
+    info = struct.pack("<IiiHH", 40, w, h, 1, 24) + b"\0" * 24
+    pad = b"\0" * ((4 - (w * 3) % 4) % 4)
+    rows = b"".join(rgb8[y, :, ::-1].tobytes() + pad for y in range(h - 1, -1, -1))
+    return head + info + rows
+
+
+@pytest.mark.parametrize("w,h", [(5, 3), (8, 2), (7, 7), (1, 1)])
+def test_sinks_bmp_ppm_bytes(tmp_path, w, h):
+    rng = np.random.Generator(np.random.PCG64(w * 100 + h))
+    planes = [rng.integers(0, 65536, (h, w)).astype(np.uint16) for _ in range(3)]
+    rgb = F.planes_to_rgb8(*planes)
+    assert np.array_equal(rgb, np.stack([p >> 8 for p in planes], 2).astype(np.uint8))      # value / 256 (render.cpp:1379-1382)
+    low = F.planes_to_rgb8(*planes, low_byte_compat=True)
+    assert np.array_equal(low, np.stack([p & 0xFF for p in planes], 2).astype(np.uint8))    # writebmp.cpp:136-141's truncation
+    path = str(tmp_path / "img.bmp")
+    F.write_bmp(path, *planes)
+    assert open(path, "rb").read() == python_bmp(rgb)
+    F.write_bmp(path, *planes, low_byte_compat=True)
+    assert open(path, "rb").read() == python_bmp(low)
+    ppm = str(tmp_path / "img.ppm")
+    F.write_ppm(ppm, *planes)
+    assert open(ppm, "rb").read() == f"P6\n{w} {h}\n255\n".encode() + rgb.tobytes()
+    with pytest.raises(OSError):
+        F.write_bmp(str(tmp_path / "no_such_dir" / "x.bmp"), *planes)
+
+
+def test_mesh_scene_end_to_end_on_the_cpu_oracle(tmp_path):
+    """mesh -> camera/materials/lights -> host builders -> ORACLE render (the checker; the product's render path needs a GPU and
+    is covered by tests/test_frontend_gpu.py) -> BMP.  Checks that the front-end's arrays are a scene the hot path accepts and
+    that the picture is a picture: lit, not saturated, different materials visible."""
+    sc = FC.room_scene(96, 72, samples=1)
+    assert sc.triangle_count == 10 + 12 + 4 + 2 * 60 and sc.material_count == 4 and sc.light_count == 2
+    assert sc.light_radius.tolist() == [f32(0.52)] * 2 and np.isinf(sc.light_half_att).all()
+    assert np.allclose(np.linalg.norm(sc.light_dir[:, :3], axis=1), 1, atol=1e-6)
+    R.build_lists(sc, threads=4)
+    r, g, b = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    assert (r > 0).mean() > 0.7 and (r == 65535).mean() < 0.2 and len(np.unique(r >> 8)) > 20
+    path = str(tmp_path / "room.bmp")
+    F.write_bmp(path, r, g, b)
+    assert open(path, "rb").read() == python_bmp(np.stack([r >> 8, g >> 8, b >> 8], 2).astype(np.uint8))
