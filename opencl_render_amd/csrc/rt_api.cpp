@@ -26,7 +26,7 @@
 extern "C" hipError_t rtk_launch_trace(const RtDevScene *scene, int counted, hipStream_t stream);
 extern "C" hipError_t rtk_launch_prepare(uint32_t triangleCount, const void *vertex, const void *triIndex, const void *triMaterial,
                                          const void *triUv, const void *triNormal, float *triRec, float *triShade, hipStream_t stream);
-extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const float *triRec, float *pairRec, hipStream_t stream);
+extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const uint32_t *pairInfo, const float *triRec, float *pairRec, hipStream_t stream);
 extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
                                         uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream);
 
@@ -308,8 +308,21 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 block[3 * b + 1] = (uint32_t)(bits[b] >> 32);
                 block[3 * b + 2] = rank[b];
             }
-            std::vector<uint2> range(cellFirst.size() - 1);
-            for (size_t k = 0; k + 1 < cellFirst.size(); ++k) range[k] = make_uint2(cellFirst[k], cellFirst[k + 1]);
+            // pair order on the device: the first candidate of every non-empty cell at the cell's dense id, then everybody's
+            // further candidates (rt_device.h, pairRec)
+            const size_t nCells = cellFirst.size() - 1;
+            std::vector<uint32_t> pairOrder(pairTri.size()), pairCount(pairTri.size(), 0u), cellRest(nCells ? nCells : 1, 0u);
+            {
+                size_t restAt = nCells;
+                for (size_t k = 0; k < nCells; ++k) {
+                    const uint32_t first = cellFirst[k], n = cellFirst[k + 1] - first;
+                    pairOrder[k] = pairTri[first];
+                    pairCount[k] = n;
+                    cellRest[k] = (uint32_t)restAt;
+                    for (uint32_t i = 1; i < n; ++i) pairOrder[restAt++] = pairTri[first + i];
+                }
+                if (restAt != pairTri.size()) return fail("internal: pair order covers %zu of %zu pairs", restAt, pairTri.size());
+            }
             {
                 std::vector<uint32_t> sparse((size_t)3 * ((63u << 16 | 63u << 8 | 63u) + 1u), 0u);
                 for (size_t b = 0; b < blocks; ++b) {
@@ -319,15 +332,19 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 if (sc->upload(sparse.data(), sparse.size(), &D.gridBlockSparse, "gridBlockSparse")) return -1;
                 HIP_OK(hipStreamSynchronize(sc->stream)); // `sparse` is freed at the end of this scope
             }
-            if (sc->upload(range.data(), range.size(), &D.cellRange, "cellRange")) return -1;
-            D.cellCount = (uint32_t)range.size();
-            uint32_t *dPairTri = nullptr;
+            if (sc->upload(cellRest.data(), nCells, &D.cellRest, "cellRest")) return -1;
+            D.cellCount = (uint32_t)nCells;
+            uint32_t *dPairTri = nullptr, *dPairCount = nullptr;
             DevScratch scratch;
             HIP_OK(scratch.get((void **)&dPairTri, (size_t)listSize * 4));
-            if (listSize) HIP_OK(hipMemcpyAsync(dPairTri, pairTri.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
+            HIP_OK(scratch.get((void **)&dPairCount, (size_t)listSize * 4));
+            if (listSize) {
+                HIP_OK(hipMemcpyAsync(dPairTri, pairOrder.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
+                HIP_OK(hipMemcpyAsync(dPairCount, pairCount.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
+            }
             float *pairRec = nullptr;
             if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
-            HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, dPairTri, D.triRec, pairRec, sc->stream));
+            HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, dPairTri, dPairCount, D.triRec, pairRec, sc->stream));
             HIP_OK(hipStreamSynchronize(sc->stream));
             D.pairRec = pairRec;
             HIP_OK(hipStreamSynchronize(sc->stream));
@@ -407,7 +424,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
         // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
         // result, staging + sorted entry
-        const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + 6 * (2 * 64 + 4) + 16;
+        uint32_t extraFactor = 6; // region B of the entry arrays, in units of the path capacity: a region-cut ray has up to 9 extra entries
+        if (const char *b = getenv("RT_WF_EXTRA_FACTOR")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) extraFactor = (uint32_t)v; }
+        const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 8) + 16;
         // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
         // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
         uint64_t budget = 24ull << 30;
@@ -440,6 +459,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         };
         parse_list(getenv("RT_WF_SEG"), segLen, 4);
         parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
+        // rounds with at least this many rays are cut at region boundaries and traced region by region (rt_wavefront.hip, wf_setup_kernel)
+        uint32_t regionRays = 0xffffffffu; // off by default: measured slower than length order once a cell visit is one fabric request
+        if (const char *b = getenv("RT_WF_REGION_RAYS")) regionRays = (uint32_t)strtoul(b, nullptr, 10);
         uint32_t spinLimit = 16384u; // a ray makes at most 766 cell visits = 96 walk phases; RT_WF_SPIN_LIMIT lowers the guard to test its error path
         if (const char *b = getenv("RT_WF_SPIN_LIMIT")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) spinLimit = (uint32_t)v; }
         uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
@@ -470,8 +492,9 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             for (int i = 0; i < 4; ++i) Wf.segLen[i] = segLen[i];
             for (int i = 0; i < 3; ++i) Wf.segRays[i] = segRays[i];
             Wf.appendRays = appendRays;
+            Wf.regionRays = regionRays;
             const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
-            const uint64_t extraCap = qcap; // room for the extra segments of long rays (a round that would need more cuts fewer rays)
+            const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the extra segments of cut rays (a workgroup that finds it full leaves its rays whole)
             const uint64_t ecap = qcap + extraCap;
             if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
             Wf.extraCap = (uint32_t)extraCap;

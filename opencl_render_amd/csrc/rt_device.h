@@ -51,13 +51,17 @@ struct RtDevScene {
     //                     block is 3*(cell & 0xFCFCFC) for a cell packed cx | cy<<8 | cz<<16 (two instructions):
     //                     50 MB of address space, 3 MiB of touched lines
     //   dense cell id     k = rank + popcount(word & ((1<<bit)-1)), bit = (cx&3) | (cy&3)<<2 | (cz&3)<<4
-    //   cellRange[k]      {first, last} pair index range of the cell (one 8-byte load)
-    //   pairRec[i]        64-byte record of pair i, replicated per (cell, triangle) pair so a cell's candidates are
-    //                     contiguous: {a.xyz, triangleId} {n.xyz, -} {ab.xyz, abab} {ac.xyz, acac}
-    //                     (abac and 1/(abac^2-abab*acac) are recomputed in the test)
+    //   pairRec[i]        64-byte record of a (cell, triangle) pair: {a.xyz, triangleId} {n.xyz, count} {ab.xyz, abab} {ac.xyz, acac}
+    //                     (abac and 1/(abac^2-abab*acac) are recomputed in the test).  Records [0, cellCount) are the FIRST
+    //                     candidate of cell k at index k itself, `count` = candidates of the cell: a cell visit is ONE
+    //                     dependent gather (the typical cell of a fine scene holds one triangle), where a {first, last} range
+    //                     table in between cost a second 128-byte fabric request per visit (profiles/r02_*: the trace kernel
+    //                     runs at ~90 % of the chip's L2-miss request rate, two requests per occupied cell).  The further
+    //                     candidates of cell k, in list order, sit at cellRest[k] .. cellRest[k] + count - 2 (records
+    //                     [cellCount, pairs), `count` field unused).
     const uint32_t *gridBlockSparse;
-    const uint2 *cellRange;
-    uint32_t cellCount; // non-empty cells = entries of cellRange
+    const uint32_t *cellRest;
+    uint32_t cellCount; // non-empty cells
     const float *pairRec;
     // materials
     uint32_t materialCount, texelCount;
@@ -88,6 +92,10 @@ struct RtDevScene {
 #define RT_WF_QSHARDS (2 * RT_WF_SHARDS) // queue slices: [0,SHARDS) main requests (one per waiting path), [SHARDS,2*SHARDS) look-ahead requests
 #define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input (wf_setup_kernel), 0 = longest
 #define RT_WF_SORT_COPIES 4   // independent histograms (workgroup % copies) to spread the atomics
+#define RT_WF_ORDER_LENGTH 0u
+#define RT_WF_ORDER_APPENDED 1u
+#define RT_WF_ORDER_REGION 2u
+#define RT_WF_REGION_SHIFT 6  // a region is 64 x 64 x 64 cells: 4 x 4 x 4 = 64 regions = RT_WF_SORT_BINS
 // host-visible status words of a tile group (RtWavefront::hostStatus)
 #define RT_WF_STATUS_ERROR 0  // RT_WF_ERR_* bits, sticky until the host clears them
 #define RT_WF_STATUS_WORDS 16
@@ -138,8 +146,11 @@ struct RtWavefront {
     uint32_t *sortExtra;       // [1] entries in region B this round
     uint32_t extraCap;         // capacity of region B (multiple of 256)
     uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
-    uint32_t *sortTotal;       // [2] entries at the front of the sorted array | 1 if the round was appended (region B holds entries too)
+    uint32_t *sortTotal;       // [2] entries at the front of the sorted array | how the round was ordered: 0 by walk length, 1 appended (region B
+                               // holds entries too), 2 by grid region (RT_WF_ORDER_*)
     uint32_t appendRays;       // rounds with fewer rays than this skip the counting sort (RT_WF_APPEND_RAYS, default 150000)
+    uint32_t regionRays;       // rounds with at least this many rays are cut at REGION boundaries and sorted by region (RT_WF_REGION_RAYS;
+                               // 0xffffffff = never): see wf_setup_kernel
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

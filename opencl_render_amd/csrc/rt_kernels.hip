@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void rt_detile_kernel(const uint16_t *__restri
 
 // Builds the (cell, triangle) pair records of the dense grid view from the per-triangle records (rt_device.h).
 // One thread per pair.
-__global__ __launch_bounds__(256) void rt_gather_pair_records(uint32_t pairCount, const uint32_t *__restrict__ pairTri,
+__global__ __launch_bounds__(256) void rt_gather_pair_records(uint32_t pairCount, const uint32_t *__restrict__ pairTri, const uint32_t *__restrict__ pairInfo,
                                                               const float4 *__restrict__ triRec, float4 *__restrict__ pairRec)
 {
     const uint32_t pair = blockIdx.x * 256 + threadIdx.x;
@@ -355,16 +355,16 @@ __global__ __launch_bounds__(256) void rt_gather_pair_records(uint32_t pairCount
     const float4 r0 = triRec[(size_t)tri * 4], r1 = triRec[(size_t)tri * 4 + 1], r2 = triRec[(size_t)tri * 4 + 2], r3 = triRec[(size_t)tri * 4 + 3];
     float4 *out = pairRec + (size_t)pair * 4;
     out[0] = make_float4(r0.x, r0.y, r0.z, __uint_as_float(tri)); // a, triangle id
-    out[1] = make_float4(r2.y, r2.z, r2.w, 0.f);                   // n
+    out[1] = make_float4(r2.y, r2.z, r2.w, __uint_as_float(pairInfo[pair])); // n, candidates of the cell (first records only)
     out[2] = make_float4(r0.w, r1.x, r1.y, r3.x);                  // ab, abab
     out[3] = make_float4(r1.z, r1.w, r2.x, r3.z);                  // ac, acac
 }
 
 // ---- launch wrappers (called from rt_api.cpp; keep every <<< >>> in this translation unit) -----------------------
-extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const float *triRec, float *pairRec, hipStream_t stream)
+extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const uint32_t *pairInfo, const float *triRec, float *pairRec, hipStream_t stream)
 {
     if (pairCount == 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_gather_pair_records, dim3((pairCount + 255) / 256), dim3(256), 0, stream, pairCount, pairTri,
+    hipLaunchKernelGGL(rt_gather_pair_records, dim3((pairCount + 255) / 256), dim3(256), 0, stream, pairCount, pairTri, pairInfo,
                        (const float4 *)triRec, (float4 *)pairRec);
     return hipGetLastError();
 }

@@ -664,7 +664,13 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     // every ray compactly at the front (sortTotal counts them), further segments in region B (sortExtra counts them), and
     // wf_scatter_kernel finds nothing to do.
     const bool append = roundRays < W.appendRays;
-    if (append && blockIdx.x == 0 && threadIdx.x == 0) W.sortTotal[1] = 1u; // tells the trace kernel that region B is in use
+    if (append && blockIdx.x == 0 && threadIdx.x == 0) W.sortTotal[1] = RT_WF_ORDER_APPENDED; // tells the trace kernel that region B is in use
+    // A BIG round is bound by the rate at which L2 misses are served (profiles/r02_*: 36 M 128-byte fabric requests per frame at
+    // ~90 % of the measured random-gather ceiling): its rays meet the same cells at unrelated times, so nearly every cell visit
+    // misses L2.  Such a round is cut at REGION boundaries instead (a region = 64^3 cells, 1/64 of the grid: ~2 MB of pair
+    // records and cell ranges, half an XCD's L2) and its entries are ordered by region; wf_trace_kernel hands every XCD a
+    // contiguous stretch of that order, so the workgroups in flight on an XCD work in the same one or two regions.
+    const bool regionMode = !append && roundRays >= W.regionRays;
     // Queue slices are sized for the worst case and filled evenly, so the work items are (slice, 256-entry block) pairs up to the
     // longest slice, taken block-major by a fixed grid (a grid over the whole capacity is mostly workgroups that exit at once:
     // ~0.35 us per 1000 of them, a quarter of a millisecond per 4K frame).
@@ -689,6 +695,9 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     uint32_t excluded = RT_NONE, endCell = 0xffffffffu, lastCell = 0, visits = 1, nseg = 0;
     DdaState cur;
     cur.cell = 0; cur.dx = 0.f; cur.dy = 0.f; cur.dz = 0.f;
+    float cut[9]; // region mode: the ray's cut parameters in ascending order, +inf when there are fewer
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cut[i] = RT_INF;
     if (active) {
         W.hitKey[mine] = ~0ull; // no segment of this request has a hit yet
         const float4 ro = W.reqO[in][mine], rd = W.reqD[in][mine];
@@ -736,7 +745,35 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         const float ta = fminf(cur.dx, fminf(cur.dy, cur.dz));
         const bool plain = !(tmax < RT_INF) && d.x != 0.f && d.y != 0.f && d.z != 0.f && te < RT_INF && -RT_INF < ta && ta < te &&
                            cur.dx == cur.dx && cur.dy == cur.dy && cur.dz == cur.dz && cur.dx < RT_INF && cur.dy < RT_INF && cur.dz < RT_INF;
-        if (plain && visits > segLen + segLen / 4) { // a ray only slightly over the aim is left whole
+        if (plain && regionMode) {
+            // Cut points = the parameters at which the ray crosses a region boundary plane (plane index 64, 128, 192 of an axis,
+            // ahead of the start cell in the direction of travel): the same rounded quotients the walk compares, so each is a
+            // legal cut (the state after all crossings with T <= tau), and between two consecutive ones the walk stays inside
+            // one region.  At most three per axis; those at or beyond the exit do not cut anything.
+            const float ta0 = fminf(cur.dx, fminf(cur.dy, cur.dz));
+            const float oa[3] = { o.x, o.y, o.z }, da[3] = { d.x, d.y, d.z };
+            const int c0[3] = { cx, cy, cz };
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int j = 1; j <= 3; ++j) {
+                    const int p = j << RT_WF_REGION_SHIFT;
+                    const bool ahead = (0.f <= da[a]) ? (p > c0[a]) : (p <= c0[a]);
+                    const float T = (planes[a * (RT_GRID_DIV + 1) + p] - oa[a]) / da[a];
+                    cut[a * 3 + j - 1] = (ahead && ta0 <= T && T < te) ? T : RT_INF;
+                }
+            }
+            // ascending order, unused slots (+inf) last: a 9-input sorting network (25 compare-exchanges)
+#define RT_CX(i, j) { const float lo_ = fminf(cut[i], cut[j]), hi_ = fmaxf(cut[i], cut[j]); cut[i] = lo_; cut[j] = hi_; }
+            RT_CX(0, 1) RT_CX(3, 4) RT_CX(6, 7) RT_CX(1, 2) RT_CX(4, 5) RT_CX(7, 8) RT_CX(0, 1) RT_CX(3, 4) RT_CX(6, 7) RT_CX(0, 3) RT_CX(3, 6) RT_CX(0, 3)
+            RT_CX(1, 4) RT_CX(4, 7) RT_CX(1, 4) RT_CX(2, 5) RT_CX(5, 8) RT_CX(2, 5) RT_CX(1, 3) RT_CX(5, 7) RT_CX(2, 6) RT_CX(4, 6) RT_CX(2, 4) RT_CX(2, 3)
+            RT_CX(5, 6)
+#undef RT_CX
+            uint32_t n = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) n += (cut[i] < RT_INF) ? 1u : 0u;
+            nseg = n + 1u;
+        } else if (plain && visits > segLen + segLen / 4) { // a ray only slightly over the aim is left whole
             nseg = (visits + segLen - 1) / segLen;
             if (nseg > RT_WF_MAXSEG) nseg = RT_WF_MAXSEG;
         }
@@ -795,7 +832,12 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         uint32_t segEnd = endCell;
         bool last = (k + 1 == nseg);
         if (!last) {
-            const float tau = ta + (te - ta) * ((float)(k + 1) / (float)nseg);
+            float tau = ta + (te - ta) * ((float)(k + 1) / (float)nseg);
+            if (regionMode) { // cut[k], picked without indexing registers dynamically
+                tau = cut[0];
+#pragma unroll
+                for (int i = 1; i < 9; ++i) tau = (k == (uint32_t)i) ? cut[i] : tau;
+            }
             if (ta <= tau && tau < te) {
                 const uint32_t c0 = cur.cell & 255u, c1 = (cur.cell >> 8) & 255u, c2 = cur.cell >> 16;
                 // crossings already made by `cur` have T <= tau_k <= tau, so counting from cur's cell is counting from the start
@@ -810,7 +852,9 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         if ((int)v < 1) v = 1;
         if (v > 767u) v = 767u;
         // two scales: segments of a finely cut round differ by a few visits, uncut rays by hundreds; bin 0 = longest
-        const uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+        uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+        if (regionMode) // the region the segment starts in: 2 bits per axis
+            bin = ((cur.cell >> RT_WF_REGION_SHIFT) & 3u) | (((cur.cell >> (8 + RT_WF_REGION_SHIFT)) & 3u) << 2) | (((cur.cell >> (16 + RT_WF_REGION_SHIFT)) & 3u) << 4);
         if (append) { // final place (same layout as a staged entry: no tag, segment in the top byte of the last word)
             uint4 *e = W.sortedEnt + 4 * (size_t)(k == 0 ? appendAt : extraAt + k - 1);
             e[0] = make_uint4(mine, cur.cell, segEnd, excluded);
@@ -884,7 +928,10 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
         uint32_t at = incl - sum;
 #pragma unroll
         for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { base[threadIdx.x * RT_WF_SORT_COPIES + c] = at; at += h[c]; }
-        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) { W.sortTotal[0] = incl; W.sortTotal[1] = 0u; } // all entries are in [0, total)
+        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) { // all entries are in [0, total)
+            W.sortTotal[0] = incl;
+            W.sortTotal[1] = (raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3] >= W.regionRays) ? RT_WF_ORDER_REGION : RT_WF_ORDER_LENGTH;
+        }
     }
     __syncthreads();
     const uint32_t usedBlocks = (max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3])) + 255u) >> 8;
@@ -930,7 +977,7 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 //   * an occupied cell is recorded as its packed coordinates only; the dense cell id (rank + popcount) is worked out in the
 //     test phase, where all 64 lanes have an item, instead of in the walk, where 6 of 64 lanes are on an occupied cell.
 #ifndef RT_WF_LEAN_WAVES
-#define RT_WF_LEAN_WAVES 4
+#define RT_WF_LEAN_WAVES 5
 #endif
 #ifndef RT_WF_LEAN_LIST
 #define RT_WF_LEAN_LIST 16            // per-lane LDS slots: recorded occupied cells + the cells logged by the current blind phase
@@ -950,10 +997,27 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
 
     // entries [0, total) and -- in an appended round -- the extra segments in region B, which follow in 64-entry chunks
     const uint32_t total = W.sortTotal[0];
-    const bool appended = W.sortTotal[1] != 0u;
+    const uint32_t order = W.sortTotal[1];
+    const bool appended = order == RT_WF_ORDER_APPENDED;
     const uint32_t extra = appended ? min(W.sortExtra[0], W.extraCap) : 0u;
     const uint32_t chunksA = (total + 63u) >> 6, chunksB = (extra + 63u) >> 6;
-    if (blockIdx.x * 4 >= chunksA + chunksB) return; // whole workgroup beyond the entries
+    // Which 256 entries this workgroup takes.  Ordered by length: workgroup i takes block i, so the longest walks start first.
+    // Ordered by region: the hardware deals consecutive workgroups round-robin to the 8 XCDs (placement is a speed matter
+    // only, nothing depends on it), so workgroup i takes block (i % 8) * blocksPerXcd + i / 8 -- every XCD works its way
+    // through ONE contiguous eighth of the region-ordered entries and its L2 holds the one or two regions it is in.
+    const uint32_t blocksUsed = (chunksA + chunksB + 3u) >> 2;
+    uint32_t blockAt = blockIdx.x;
+    if (order == RT_WF_ORDER_REGION) {
+        const uint32_t perXcd = (blocksUsed + 7u) >> 3;
+        blockAt = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= perXcd) return;
+    }
+#ifdef RT_WF_INTERLEAVE
+    // length order, taken from both ends: even workgroups the longest walks left, odd ones the shortest -- a SIMD then holds
+    // waves that are walking (VALU) next to waves that are mostly testing (memory)
+    if (order == RT_WF_ORDER_LENGTH && blockIdx.x < blocksUsed) blockAt = (blockIdx.x & 1u) ? blocksUsed - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+#endif
+    if (blockAt >= blocksUsed) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
@@ -962,7 +1026,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // slot always gets the longest work left.  (Fixed grids whose waves stride over the array, or take chunks from a shared
     // cursor, were 23 % and 11 % slower; the price of this grid is ~0.35 us per 1000 workgroups that find nothing to do.)
     for (uint32_t once = 0; once < 1u; ++once) {
-    const uint32_t chunk = blockIdx.x * 4 + wave;
+    const uint32_t chunk = blockAt * 4 + wave;
     if (chunk >= chunksA + chunksB) break;
     const bool inB = chunk >= chunksA;
     const uint32_t mine = inB ? 2u * W.capacity + (chunk - chunksA) * 64 + lane : chunk * 64 + lane;
@@ -986,8 +1050,6 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     const uint32_t stepX = px ? 1u : (uint32_t)-1, stepY = py ? (1u << 8) : (uint32_t)-(1 << 8), stepZ = pz ? (1u << 16) : (uint32_t)-(1 << 16);
     // byte offset into `planes` of the plane that bounds the NEW cell ahead: 4*(axisBase + c + (positive ? 1 : 0))
     const uint32_t offX = 4u * (px ? 1u : 0u), offY = 4u * ((RT_GRID_DIV + 1) + (py ? 1u : 0u)), offZ = 4u * (2 * (RT_GRID_DIV + 1) + (pz ? 1u : 0u));
-    // coordinate at which a further step leaves the grid (:389,:393,:397), packed like the cell
-    const uint32_t lastCell = (px ? 255u : 0u) | ((py ? 255u : 0u) << 8) | ((pz ? 255u : 0u) << 16);
     const char *__restrict__ blockTable = reinterpret_cast<const char *>(S.gridBlockSparse);
     const char *planeBytes = reinterpret_cast<const char *>(planes);
 
@@ -1035,9 +1097,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                         const bool sxm = (dx < dy) & (dx < dz);
                         const bool sym = !sxm & (dy < dz);
                         const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);
-                        done = ((((cell ^ lastCell) >> shift) & 255u) == 0u); // the step would leave the grid
+                        const uint32_t stepSel = sxm ? stepX : (sym ? stepY : stepZ);
+                        // the step would leave the grid (:389,:393,:397): coordinate 255 going up, 0 going down
+                        done = (((cell >> shift) & 255u) == (((int32_t)stepSel > 0) ? 255u : 0u));
                         if (!done) {
-                            cell += sxm ? stepX : (sym ? stepY : stepZ);
+                            cell += stepSel;
                             const uint32_t off = sxm ? offX : (sym ? offY : offZ);
                             const float plane = *reinterpret_cast<const float *>(planeBytes + (((cell >> shift) & 255u) << 2) + off);
                             const float dd = sxm ? d.x : (sym ? d.y : d.z);
@@ -1049,30 +1113,33 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                     walkEnded = done;
                 }
             }
-            // look-up: which of the logged cells are occupied?  Keep those, in path order, at the front of the list.
-            uint32_t lc[RT_WF_BLIND], lkey[RT_WF_BLIND];
+            // look-up: which of the logged cells are occupied?  Keep those, in path order, at the front of the list.  Only the
+            // requested words stay in registers across the wait; the logged cells are read back from LDS on both sides of it
+            // (what a word is needed for -- "the block differs from the one before" -- is recomputed the same way).
             uint2 lw[RT_WF_BLIND];
-            bool lneed[RT_WF_BLIND];
             {
                 uint32_t prev = wordKey;
 #pragma unroll
                 for (int i = 0; i < RT_WF_BLIND; ++i) {
-                    lc[i] = ((uint32_t)i < logged) ? cellList[listed + i][threadIdx.x] : 0u;
-                    lkey[i] = lc[i] & 0xFCFCFCu;
-                    lneed[i] = ((uint32_t)i < logged) && lkey[i] != prev;
                     lw[i] = make_uint2(0u, 0u);
-                    if (lneed[i]) { lw[i] = *reinterpret_cast<const uint2 *>(blockTable + (size_t)(lkey[i] * 3u)); prev = lkey[i]; }
+                    if ((uint32_t)i < logged) {
+                        const uint32_t key = cellList[listed + i][threadIdx.x] & 0xFCFCFCu;
+                        if (key != prev) { lw[i] = *reinterpret_cast<const uint2 *>(blockTable + (size_t)(key * 3u)); prev = key; }
+                    }
                 }
             }
+            const uint32_t listedBefore = listed;
 #pragma unroll
             for (int i = 0; i < RT_WF_BLIND; ++i) {
                 if ((uint32_t)i < logged) {
-                    if (lneed[i]) { wordKey = lkey[i]; wordLo = lw[i].x; wordHi = lw[i].y; }
+                    const uint32_t c = cellList[listedBefore + i][threadIdx.x]; // slot listedBefore + i >= listed: not overwritten yet
+                    const uint32_t key = c & 0xFCFCFCu;
+                    if (key != wordKey) { wordKey = key; wordLo = lw[i].x; wordHi = lw[i].y; }
                     // bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 : gather the three 2-bit fields with one multiply
-                    const uint32_t bit = (((lc[i] & 0x030303u) * 0x1041u) >> 12) & 63u;
-                    const uint32_t half = (lc[i] & 0x20000u) ? wordHi : wordLo; // bit 5 of `bit` is bit 1 of cz
+                    const uint32_t bit = (((c & 0x030303u) * 0x1041u) >> 12) & 63u;
+                    const uint32_t half = (c & 0x20000u) ? wordHi : wordLo; // bit 5 of `bit` is bit 1 of cz
                     if ((half >> (bit & 31u)) & 1u) {
-                        cellList[listed][threadIdx.x] = lc[i];
+                        cellList[listed][threadIdx.x] = c;
                         ++listed;
                     }
                 }
@@ -1089,6 +1156,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         // are tested with the reference's running maximum (:366-379); the owner's answer is the hit of its EARLIEST cell
         // (:380), found with an LDS atomicMin on (cell order, pair index); the owner then re-evaluates that one pair.
         {
+            wordKey = 0xffffffffu; // the cached occupancy word is not carried across the test phase (three registers at the kernel's peak)
             const uint32_t mineN = listed;
             uint32_t incl = mineN;
 #pragma unroll
@@ -1125,22 +1193,25 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                         const uint32_t bit = (pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u);
                         const unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;
                         const uint32_t dense = rank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
-                        const uint2 range = S.cellRange[dense];
                         uint32_t bestPair = RT_NONE;
                         float tbest = ptmax; // running maximum, reset per cell (:366)
-                        // software pipeline: the next candidate's record is requested before the current one is tested
-                        const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)range.x;
-                        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-                        if (range.x < range.y) { r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
-                        for (uint32_t i = range.x; i < range.y; ++i) {
-                            float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3;
-                            if (i + 1 < range.y) { n0 = rec[4]; n1 = rec[5]; n2 = rec[6]; n3 = rec[7]; }
-                            rec += 4;
+                        // the cell's first candidate sits at the dense id itself (rt_device.h, pairRec) and says how many there are
+                        const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)dense;
+                        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                        const uint32_t count = __float_as_uint(r1.w);
+                        {
                             float t, l1, l2;
-                            if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, tbest, pexcl, t, l1, l2)) {
-                                bestPair = i; tbest = t;
+                            if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, tbest, pexcl, t, l1, l2)) { bestPair = dense; tbest = t; }
+                        }
+                        if (count > 1u) { // further candidates, in list order (rare in a fine scene: no prefetch, registers matter more)
+                            const uint32_t restAt = S.cellRest[dense];
+                            rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)restAt;
+#pragma unroll 1
+                            for (uint32_t i = 0; i + 1 < count; ++i, rec += 4) {
+                                r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+                                float t, l1, l2;
+                                if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, tbest, pexcl, t, l1, l2)) { bestPair = restAt + i; tbest = t; }
                             }
-                            r0 = n0; r1 = n1; r2 = n2; r3 = n3;
                         }
                         if (bestPair != RT_NONE)
                             atomicMin((unsigned long long *)&keys[owner], ((unsigned long long)j << 32) | (unsigned long long)bestPair);

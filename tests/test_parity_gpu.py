@@ -199,6 +199,9 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
     {"RT_WF_LOOKAHEAD": "0"},                              # one ray in flight per path
     {"RT_WF_GROUPS": "3"},                                 # three concurrent tile groups per instance
     {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1", "RT_WF_LOOKAHEAD": "0"},
+    {"RT_WF_REGION_RAYS": "1", "RT_WF_APPEND_RAYS": "0"},   # every round cut at region boundaries and traced region by region
+    {"RT_WF_REGION_RAYS": "1", "RT_WF_APPEND_RAYS": "0", "RT_WF_EXTRA_FACTOR": "1", "RT_WF_LOOKAHEAD": "0"},  # ... with a region B that overflows
+    {"RT_WF_REGION_RAYS": "4000000000"},                   # never
 ])
 def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
     """Ray segmentation (the DDA state at a ray parameter is computed without walking, segments are traced independently and
