@@ -6,7 +6,8 @@
 
 A "step" is one frame: every rank renders its 128x128 tiles of the frame (one launch of the trace kernel over the
 scene resident in its HBM), the tile buffers are gathered to rank 0 (RCCL) and rank 0 scatters them into the three
-row-major u16 planes on its device.  Inputs are resident before the timed region; outputs stay on the device.
+row-major u16 planes on its device.  Inputs are resident before the timed region; outputs stay on the device for
+`value` / `ms_per_step`; `ms_per_frame_with_d2h` is the same loop with the planes copied to pinned host memory every frame.
 The same frame is split over more GPUs as N grows => "scaling": "strong".
 
 Workloads (synthetic seeded triangle soups, lists built by the library's host builders):
@@ -178,8 +179,33 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # The timed frames were issued from a launch plan, without looking at the ray queue (rtHipFrameFinish): now that the
+    # device is idle, check that every one of them really was complete.  A frame that was not voids the run.
+    if rs.finish():
+        sys.exit("bench.py: a timed frame needed more rounds than its launch plan issued -- timing is void")
     if rank == 0:
         log(f"timed {args.steps} frames: {1e3 * elapsed / args.steps:.3f} ms/frame")
+    # ---- the same frames once more with the three planes copied to (pinned) host memory at the end of every frame, on the
+    # frame's stream: ms/frame as SURVEY 8(d) defines it (t_kernel + t_gather + D2H).  `value` stays the device-resident rate.
+    ms_with_d2h = None
+    if rank == 0:
+        host_planes = torch.empty(3 * P * 2, dtype=torch.uint8, pin_memory=True)
+    for _ in range(2):
+        frame()
+        if rank == 0:
+            host_planes.copy_(planes, non_blocking=True)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+        if rank == 0:
+            host_planes.copy_(planes, non_blocking=True)
+    torch.cuda.synchronize()
+    barrier()
+    ms_with_d2h = 1e3 * (time.perf_counter() - t1) / args.steps
+    if rs.finish():
+        sys.exit("bench.py: a timed frame needed more rounds than its launch plan issued -- timing is void")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,20 +253,26 @@ def main():
         # HBM bytes of the dominant kernel per frame from the PMC passes committed under profiles/ (collected by
         # scripts/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 x2 read correction);
         # only reported when that profile is of this very workload and N=1
-        traffic = None
+        # `traffic` is NOT measured by this run (counters need rocprofv3): it is the fabric (L2-miss) bytes of the dominant kernel
+        # per frame from the counter passes committed under profiles/ -- TCC_EA0_RDREQ x 128 B, every request of this kernel is
+        # a 128-byte one (profiles/r02_*) -- and is tagged with the file and the commit it was taken at.  Only given when that
+        # profile is of this very workload, S=1, N=1.
+        traffic = traffic_source = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic_lambert1m.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_trace_fabric_traffic.json")))
             key = dom_name.split(" ")[0]
             if world == 1 and pipeline and prof.get("workload") == args.workload and args.samples == 1 and key in prof["per_frame"]:
-                traffic = int(prof["per_frame"][key]["hbm_bytes"])
+                traffic = int(prof["per_frame"][key]["fabric_read_bytes"] + prof["per_frame"][key].get("write_bytes", 0))
+                traffic_source = f"profiles/r02_trace_fabric_traffic.json @ {prof.get('commit', '?')} (not measured by this run)"
         except (OSError, ValueError, KeyError):
-            traffic = None
+            traffic = traffic_source = None
         out = {
             "metric": "Mrays/s (primary rays; each also traces its shadow/bounce rays) at ms/frame = ms_per_step",
             "value": round(primary_rays * args.steps / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_frame_with_d2h": round(ms_with_d2h, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -254,7 +286,7 @@ def main():
             "total_mrays_per_s": round(total_rays * args.steps / elapsed / 1e6, 3),
             "rays_per_frame": {"primary": int(primary_rays), "grid": int(total_stats["gridRays"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dom_name, "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(dom_bytes),
                          "frame": {"device_ms": round(kernel_ms, 4), "frames": int(launches), "algorithmic_bytes": int(b_local),
                                    "achieved": round(b_local / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,

@@ -191,9 +191,18 @@ uint64_t rtHipSceneBytes(const rtHipScene *scene);
  * (a hipStream_t passed as void*; NULL = the scene's own stream).  Returns 0 on success. */
 int rtHipRenderTiles(rtHipScene *scene, void *stream);
 
+/* Frames after a scene's first are issued WITHOUT any host synchronisation (the first frame leaves a launch plan behind: how
+ * many rounds the frame needs and how big each is; frames of one scene are deterministic).  Whether such a frame really was
+ * complete is checked afterwards: rtHipSync and rtHipReadback do it themselves; a caller that consumes the tile buffer on the
+ * stream (an RCCL gather enqueued behind the frame) calls rtHipFrameFinish once its own synchronisation is over.  If the plan
+ * was too short the last frame is rendered again, watched, and *redone (optional) is set to 1: work that was enqueued behind
+ * the incomplete frame has to be repeated.  RT_WF_BLOCKING=1 makes every frame a watched one.  Returns 0 on success. */
+int rtHipFrameFinish(rtHipScene *scene, int *redone);
+
 /* Two implementations of the same frame (identical planes):
  *   WAVEFRONT (default) staged pipeline: primary -> rounds of (per-path logic, length sort of the new ray requests, grid
- *                       trace) -> ordered accumulate.  rtHipRenderTiles blocks until the frame's rounds have been issued.
+ *                       trace) -> ordered accumulate.  The first frame of a scene watches its ray queue from the host; later frames
+ *                       are issued without synchronisation (rtHipFrameFinish).
  *                       Tuning aids read at scene creation: RT_WF_LOOKAHEAD=0|1, RT_WF_SEG="a,b,c,d" and
  *                       RT_WF_SEG_RAYS="a,b,c" (ray segmentation by round size), RT_WF_APPEND_RAYS=n (rounds below n rays skip the length sort), RT_WF_GROUPS=n, RT_WF_STATE_MB.
  *   MEGAKERNEL          one launch, one thread per pixel (kept for A/B runs and for the work counters). */

@@ -32,7 +32,8 @@ extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *til
 
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_status(const RtWavefront *wf, uint32_t round, hipStream_t stream);
 extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
 extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
 
@@ -96,10 +97,18 @@ struct rtHipScene {
         uint32_t *hostCount = nullptr;  // pinned: queue length read back between round chunks
         uint32_t *hostStatus = nullptr; // pinned + mapped: RT_WF_STATUS_* words the kernels write (rt_device.h)
         uint32_t rounds = 0;
+        // launch plan (render_wavefront): what the last discovery frame needed
+        uint32_t roundsNeeded = 0;
+        uint32_t planEntries[RT_WF_ROUND_LOG] = { 0 }, planEntriesNext[RT_WF_ROUND_LOG] = { 0 };
     };
     std::vector<Group> groups;
     hipEvent_t forkEvent = nullptr;
     uint32_t samplesPerBatch = 1;
+    uint32_t planRounds = 0;   // rounds a planned frame issues per batch; 0 = no plan yet (the next frame is a discovery frame)
+    bool blocking = false;     // RT_WF_BLOCKING=1: every frame watches the queue (no plan)
+    uint32_t planCap = 0;      // RT_WF_PLAN_ROUNDS=n (test hook): planned frames issue at most n rounds, so that the too-short-plan path runs
+    bool unverified = false;   // planned frames were issued since the last frame_finish()
+    hipStream_t lastStream = nullptr; // where the last frame was issued
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum, sort]
     struct StageEvent { int stage; hipEvent_t a, b; };
     std::vector<StageEvent> stageEvents;
@@ -509,8 +518,10 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
                 sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
                 sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
                 sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
-                sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal))
+                sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal) ||
+                sc->alloc<uint32_t>(RT_WF_ROUND_LOG, &Wf.roundLog))
                 return -1;
+            HIP_OK(hipMemsetAsync(Wf.roundLog, 0, sizeof(uint32_t) * RT_WF_ROUND_LOG, sc->stream));
             HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, 2 * sizeof(uint32_t), sc->stream));
             HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
             HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
@@ -526,18 +537,29 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         }
         HIP_OK(hipStreamSynchronize(sc->stream));
         mark("path state buffers");
+        if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');
+        if (const char *b = getenv("RT_WF_PLAN_ROUNDS")) sc->planCap = (uint32_t)strtoul(b, nullptr, 10);
         const char *env = getenv("RT_HIP_PIPELINE");
         if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     }
     return 0;
 }
 
-// One frame through the staged pipeline: per sample batch and tile group -- primary, then rounds of (sort, trace, logic)
-// until no path is waiting for the grid, then the ordered accumulate.  The round count is data dependent, so the queue
-// length is read back after every chunk of rounds (one small pinned copy + stream sync per chunk and group).  Groups run
-// concurrently on their own streams, forked from and joined to `st`; with stage timing on they run one after the other on
-// `st`, so that a kernel's measured duration is its own.
-int render_wavefront(rtHipScene *sc, hipStream_t st)
+// One frame through the staged pipeline: per sample batch and tile group -- primary, then rounds of (sort, trace, logic) until
+// no path is waiting for the grid, then the ordered accumulate.  The round count is data dependent.
+//
+// DISCOVERY frame (the first frame of a scene, or RT_WF_BLOCKING=1): rounds are issued in chunks and the queue length is read
+// back after every chunk (one small pinned copy + stream sync per chunk and group).  It leaves a PLAN behind: the number of
+// rounds the frame needed and the trace-input size of every round (RtWavefront::roundLog).
+// PLANNED frames (every later frame): the plan's rounds are issued back to back with right-sized trace grids and NO host
+// synchronisation -- whatever the caller enqueues behind the frame (the tile gather) follows immediately.  The last kernel of
+// a batch (wf_status_kernel) adds the number of paths still waiting to a mapped host word; frame_finish() looks at it after
+// the caller's own synchronisation.  A non-zero count means the plan was too short for this frame (the frames of a scene are
+// deterministic, so that only happens when something about the frame changed): the frame is rendered again as a discovery
+// frame and the caller is told, so that work enqueued behind the incomplete frame can be redone.
+// Groups run concurrently on their own streams, forked from and joined to `st`; with stage timing on they run one after the
+// other on `st`, so that a kernel's measured duration is its own.
+int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
 {
     auto stage = [&](int which, hipStream_t on, auto &&launch) -> hipError_t {
         if (!sc->stageTiming) return launch();
@@ -563,20 +585,39 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
         HIP_OK(hipEventRecord(sc->forkEvent, st));
         for (size_t g = 1; g < sc->groups.size(); ++g) HIP_OK(hipStreamWaitEvent(sc->groups[g].stream, sc->forkEvent, 0));
     }
-    // Rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds (shade
-    // the primary hits | consume shadow + bounce answers, shade the bounce hits | consume their shadow answers) with a trace
-    // before the last two, so a chunk is 3 rounds.
-    auto issue_chunk = [&](rtHipScene::Group &G, hipStream_t on) -> int {
-        const uint32_t chunk = 3;
-        for (uint32_t k = 0; k < chunk && G.rounds < RT_WF_MAX_ROUNDS; ++k, ++G.rounds) {
-            const uint32_t r = G.rounds;
-            if (r > 0) { // the requests appended by logic(r-1): sort by predicted walk length, then walk the grid
-                HIP_OK(stage(4, on, [&] { return rtw_launch_sort(&G.dev, &G.wf, r, G.queueBlocks, on); }));
-                HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, G.traceBlocks, on); }));
-            }
-            HIP_OK(stage(1, on, [&] { return rtw_launch_logic(&G.dev, &G.wf, r, G.logicBlocks, on); }));
+    const bool planned = !forceDiscovery && !sc->blocking && sc->planRounds > 0;
+    auto trace_blocks = [&](rtHipScene::Group &G, uint32_t r) -> uint32_t {
+        if (!planned || r >= RT_WF_ROUND_LOG) return G.traceBlocks;
+        // the same frame gave this many entries last time: a tenth more plus a few, never more than the worst case; the kernel
+        // strides if that should still be too few
+        const uint64_t want = ((uint64_t)G.planEntries[r] * 11 / 10 + 255) / 256 + 8;
+        return (uint32_t)std::min<uint64_t>(G.traceBlocks, std::max<uint64_t>(want, 1));
+    };
+    auto issue_round = [&](rtHipScene::Group &G, hipStream_t on) -> int {
+        const uint32_t r = G.rounds;
+        if (r > 0) { // the requests appended by logic(r-1): order them, then walk the grid
+            HIP_OK(stage(4, on, [&] { return rtw_launch_sort(&G.dev, &G.wf, r, G.queueBlocks, on); }));
+            HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, r, trace_blocks(G, r), on); }));
         }
+        HIP_OK(stage(1, on, [&] { return rtw_launch_logic(&G.dev, &G.wf, r, G.logicBlocks, on); }));
+        ++G.rounds;
+        return 0;
+    };
+    // Discovery: rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds
+    // (shade the primary hits | consume shadow + bounce answers, shade the bounce hits | consume their shadow answers) with a
+    // trace before the last two, so a chunk is 3 rounds.
+    auto issue_chunk = [&](rtHipScene::Group &G, hipStream_t on) -> int {
+        for (uint32_t k = 0; k < 3 && G.rounds < RT_WF_MAX_ROUNDS; ++k)
+            if (issue_round(G, on) != 0) return -1;
         HIP_OK(hipMemcpyAsync(G.hostCount, G.wf.counts + (G.rounds % 3) * RT_WF_QSHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, on)); // main slices
+        return 0;
+    };
+    auto device_error = [&](rtHipScene::Group &G) -> int {
+        if (const uint32_t err = G.hostStatus[RT_WF_STATUS_ERROR]) {
+            G.hostStatus[RT_WF_STATUS_ERROR] = 0u;
+            return fail("wavefront pipeline: device error 0x%x%s -- the frame is invalid", err,
+                        (err & RT_WF_ERR_SPIN) ? " (wf_trace_kernel's walk guard tripped: rays were abandoned)" : "");
+        }
         return 0;
     };
     uint64_t rounds = 0;
@@ -589,36 +630,88 @@ int render_wavefront(rtHipScene *sc, hipStream_t st)
             G.wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, sampleCount - base);
             G.rounds = 0;
             HIP_OK(hipMemsetAsync(G.wf.counts, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_QSHARDS, on));
+            if (!planned) HIP_OK(hipMemsetAsync(G.wf.roundLog, 0, sizeof(uint32_t) * RT_WF_ROUND_LOG, on));
             HIP_OK(stage(0, on, [&] { return rtw_launch_primary(&G.dev, &G.wf, on); }));
-            if (issue_chunk(G, on) != 0) return -1;
+            if (planned) {
+                while (G.rounds < sc->planRounds)
+                    if (issue_round(G, on) != 0) return -1;
+                HIP_OK(rtw_launch_status(&G.wf, G.rounds, on));
+            } else if (issue_chunk(G, on) != 0) return -1;
         }
         for (size_t g = 0; g < sc->groups.size(); ++g) {
             rtHipScene::Group &G = sc->groups[g];
             const hipStream_t on = streamOf(g);
-            for (;;) {
-                HIP_OK(hipStreamSynchronize(on));
-                if (const uint32_t err = G.hostStatus[RT_WF_STATUS_ERROR]) {
-                    G.hostStatus[RT_WF_STATUS_ERROR] = 0u;
-                    return fail("wavefront pipeline: device error 0x%x%s -- the frame is invalid", err,
-                                (err & RT_WF_ERR_SPIN) ? " (wf_trace_kernel's walk guard tripped: rays were abandoned)" : "");
+            if (!planned) {
+                for (;;) {
+                    HIP_OK(hipStreamSynchronize(on));
+                    if (device_error(G) != 0) return -1;
+                    uint64_t waiting = 0;
+                    for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += G.hostCount[i];
+                    if (waiting == 0) break;
+                    if (G.rounds >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
+                    if (issue_chunk(G, on) != 0) return -1;
                 }
-                uint64_t waiting = 0;
-                for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += G.hostCount[i];
-                if (waiting == 0) break;
-                if (G.rounds >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
-                if (issue_chunk(G, on) != 0) return -1;
+                // the plan for the frames to come: the rounds that had anything to trace (+ the logic round that consumed the last
+                // answers), and every round's trace-input size
+                uint32_t log[RT_WF_ROUND_LOG];
+                HIP_OK(hipMemcpyAsync(log, G.wf.roundLog, sizeof log, hipMemcpyDeviceToHost, on));
+                HIP_OK(hipStreamSynchronize(on));
+                uint32_t needed = 1; // logic(0) always runs
+                for (uint32_t r = 1; r < std::min<uint32_t>(G.rounds, RT_WF_ROUND_LOG); ++r)
+                    if (log[r]) needed = r + 1;
+                if (G.rounds > RT_WF_ROUND_LOG) needed = G.rounds;
+                G.roundsNeeded = std::max(G.roundsNeeded, needed);
+                for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) G.planEntriesNext[r] = std::max(G.planEntriesNext[r], log[r]);
             }
             rounds = std::max<uint64_t>(rounds, G.rounds);
             if (sampleCount > 1) // a one-sample frame's pixels were written by the kernels that finished them
                 HIP_OK(stage(3, on, [&] { return rtw_launch_accum(&G.dev, &G.wf, base == 0 ? 1 : 0, on); }));
         }
     }
+    if (!planned) { // adopt what this frame needed (the maximum over its batches and groups)
+        uint32_t need = 1;
+        for (auto &G : sc->groups) {
+            need = std::max(need, G.roundsNeeded);
+            memcpy(G.planEntries, G.planEntriesNext, sizeof G.planEntries);
+            memset(G.planEntriesNext, 0, sizeof G.planEntriesNext);
+            G.roundsNeeded = 0;
+        }
+        sc->planRounds = sc->planCap ? std::min(need, sc->planCap) : need;
+    } else sc->unverified = true;
     if (!serial)
         for (size_t g = 1; g < sc->groups.size(); ++g) {
             HIP_OK(hipEventRecord(sc->groups[g].done, sc->groups[g].stream));
             HIP_OK(hipStreamWaitEvent(st, sc->groups[g].done, 0));
         }
     sc->roundsLast = rounds;
+    return 0;
+}
+
+// After the caller's synchronisation of `st`: were the planned frames since the last call complete?  If not, the LAST frame
+// is rendered again with the queue watched (earlier incomplete frames were overwritten by it anyway).  *redone (optional)
+// = 1 when that happened: whatever was enqueued behind the incomplete frame saw unfinished tiles.
+int frame_finish(rtHipScene *sc, hipStream_t st, int *redone)
+{
+    if (redone) *redone = 0;
+    if (!sc->unverified) return 0;
+    HIP_OK(hipStreamSynchronize(st));
+    for (auto &G : sc->groups)
+        if (G.stream) HIP_OK(hipStreamSynchronize(G.stream));
+    sc->unverified = false;
+    uint64_t waiting = 0;
+    for (auto &G : sc->groups) {
+        if (const uint32_t err = G.hostStatus[RT_WF_STATUS_ERROR]) {
+            G.hostStatus[RT_WF_STATUS_ERROR] = 0u;
+            return fail("wavefront pipeline: device error 0x%x%s -- the frame is invalid", err,
+                        (err & RT_WF_ERR_SPIN) ? " (wf_trace_kernel's walk guard tripped: rays were abandoned)" : "");
+        }
+        waiting += G.hostStatus[RT_WF_STATUS_WAITING];
+        G.hostStatus[RT_WF_STATUS_WAITING] = 0u;
+    }
+    if (waiting == 0) return 0;
+    if (redone) *redone = 1;
+    if (render_wavefront(sc, st, true) != 0) return -1;
+    HIP_OK(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -678,6 +771,7 @@ int rtHipRenderTiles(rtHipScene *sc, void *stream)
     if (!sc) return fail("null scene");
     HIP_OK(hipSetDevice(sc->device));
     hipStream_t st = stream ? (hipStream_t)stream : sc->stream;
+    sc->lastStream = st;
     if (sc->eventsUsed == sc->events.size()) {
         hipEvent_t a, b;
         HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
@@ -686,7 +780,7 @@ int rtHipRenderTiles(rtHipScene *sc, void *stream)
     auto &ev = sc->events[sc->eventsUsed++];
     HIP_OK(hipEventRecord(ev.first, st));
     if (sc->pipeline == RT_HIP_PIPELINE_WAVEFRONT) {
-        if (render_wavefront(sc, st) != 0) return -1;
+        if (render_wavefront(sc, st, false) != 0) return -1;
     } else {
         HIP_OK(rtk_launch_trace(&sc->dev, 0, st));
     }
@@ -771,7 +865,14 @@ int rtHipSync(rtHipScene *sc, void *stream)
     if (!sc) return fail("null scene");
     HIP_OK(hipSetDevice(sc->device));
     HIP_OK(hipStreamSynchronize(stream ? (hipStream_t)stream : sc->stream));
-    return 0;
+    return frame_finish(sc, sc->lastStream ? sc->lastStream : sc->stream, nullptr);
+}
+
+int rtHipFrameFinish(rtHipScene *sc, int *redone)
+{
+    if (!sc) return fail("null scene");
+    HIP_OK(hipSetDevice(sc->device));
+    return frame_finish(sc, sc->lastStream ? sc->lastStream : sc->stream, redone);
 }
 
 int rtHipReadback(rtHipScene *sc, cl_ushort *outR, cl_ushort *outG, cl_ushort *outB)
@@ -779,6 +880,7 @@ int rtHipReadback(rtHipScene *sc, cl_ushort *outR, cl_ushort *outG, cl_ushort *o
     if (!sc || !outR || !outG || !outB) return fail("null argument");
     HIP_OK(hipSetDevice(sc->device));
     HIP_OK(hipDeviceSynchronize());
+    if (frame_finish(sc, sc->lastStream ? sc->lastStream : sc->stream, nullptr) != 0) return -1;
     const size_t nt = sc->tileIds.size();
     std::vector<uint16_t> host(nt * 3 * RT_TILE_PIXELS);
     HIP_OK(hipMemcpy(host.data(), sc->dev.tileBuf, host.size() * 2, hipMemcpyDeviceToHost));

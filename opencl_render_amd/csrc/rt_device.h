@@ -98,7 +98,11 @@ struct RtDevScene {
 #define RT_WF_REGION_SHIFT 6  // a region is 64 x 64 x 64 cells: 4 x 4 x 4 = 64 regions = RT_WF_SORT_BINS
 // host-visible status words of a tile group (RtWavefront::hostStatus)
 #define RT_WF_STATUS_ERROR 0  // RT_WF_ERR_* bits, sticky until the host clears them
+#define RT_WF_STATUS_WAITING 1 // paths still waiting for the grid when the issued rounds of a batch were over, summed over the batches since the
+                               // host last cleared it: non-zero = the frame is INCOMPLETE (the planned number of rounds was too small)
+#define RT_WF_STATUS_BATCHES 2 // batches whose issued rounds are over (a progress count for the host)
 #define RT_WF_STATUS_WORDS 16
+#define RT_WF_ROUND_LOG 64     // rounds of a batch whose trace-input size is logged for the launch plan (RtWavefront::roundLog)
 #define RT_WF_ERR_SPIN 1u     // wf_trace_kernel's walk guard tripped: rays were abandoned, the frame is invalid
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
@@ -107,6 +111,7 @@ struct RtWavefront {
     uint32_t lookAhead;      // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
     uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (RT_WF_SPIN_LIMIT, default 16384)
     uint32_t *hostStatus;    // pinned HOST words mapped into the device (RT_WF_STATUS_*): written by kernels, read by the host after a sync
+    uint32_t *roundLog;      // [RT_WF_ROUND_LOG] entries (all segments) the trace kernel of round r found, for sizing later frames' launches
     uint32_t segLen[4];      // aimed-at cell visits per segment for rounds with >= segRays[0] | >= segRays[1] | >= segRays[2] | fewer rays
     uint32_t segRays[3];     // (RT_WF_SEG="a,b,c,d", RT_WF_SEG_RAYS="a,b,c"; defaults 4096,256,64,16 and 700000,300000,30000)
     // per-path state, indexed by path id

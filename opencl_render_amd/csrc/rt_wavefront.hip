@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 #ifndef RT_WF_LEAN_STALL
 #define RT_WF_LEAN_STALL 64           // test once (lanes without room for another phase) x this exceeds the lanes still walking
 #endif
-__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W)
+__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t cellList[RT_WF_LEAN_LIST][256];                 // [entry][thread] packed cells cx | cy<<8 | cz<<16
@@ -1006,18 +1006,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // only, nothing depends on it), so workgroup i takes block (i % 8) * blocksPerXcd + i / 8 -- every XCD works its way
     // through ONE contiguous eighth of the region-ordered entries and its L2 holds the one or two regions it is in.
     const uint32_t blocksUsed = (chunksA + chunksB + 3u) >> 2;
-    uint32_t blockAt = blockIdx.x;
-    if (order == RT_WF_ORDER_REGION) {
-        const uint32_t perXcd = (blocksUsed + 7u) >> 3;
-        blockAt = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
-        if ((blockIdx.x >> 3) >= perXcd) return;
-    }
-#ifdef RT_WF_INTERLEAVE
-    // length order, taken from both ends: even workgroups the longest walks left, odd ones the shortest -- a SIMD then holds
-    // waves that are walking (VALU) next to waves that are mostly testing (memory)
-    if (order == RT_WF_ORDER_LENGTH && blockIdx.x < blocksUsed) blockAt = (blockIdx.x & 1u) ? blocksUsed - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
-#endif
-    if (blockAt >= blocksUsed) return; // whole workgroup beyond the entries
+    if (blockIdx.x == 0 && threadIdx.x == 0 && round < RT_WF_ROUND_LOG) W.roundLog[round] = total + extra;
+    const uint32_t perXcd = (blocksUsed + 7u) >> 3;
+    const uint32_t slots = (order == RT_WF_ORDER_REGION) ? 8u * perXcd : blocksUsed; // work items a grid has to cover
+    if (blockIdx.x >= slots) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
@@ -1025,9 +1017,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // One workgroup per 256 sorted entries, dispatched by the hardware in order: the longest walks start first and a free
     // slot always gets the longest work left.  (Fixed grids whose waves stride over the array, or take chunks from a shared
     // cursor, were 23 % and 11 % slower; the price of this grid is ~0.35 us per 1000 workgroups that find nothing to do.)
-    for (uint32_t once = 0; once < 1u; ++once) {
+    // (the grid is sized from the previous frame's rounds, rt_api.cpp; a grid that turns out too small strides over the rest)
+    for (uint32_t slot = blockIdx.x; slot < slots; slot += gridDim.x) {
+    const uint32_t blockAt = (order == RT_WF_ORDER_REGION) ? (slot & 7u) * perXcd + (slot >> 3) : slot;
     const uint32_t chunk = blockAt * 4 + wave;
-    if (chunk >= chunksA + chunksB) break;
+    if (chunk >= chunksA + chunksB) continue;
     const bool inB = chunk >= chunksA;
     const uint32_t mine = inB ? 2u * W.capacity + (chunk - chunksA) * 64 + lane : chunk * 64 + lane;
     bool active = inB ? (chunk - chunksA) * 64 + lane < extra : mine < total;
@@ -1277,6 +1271,25 @@ __global__ __launch_bounds__(256) void wf_accum_kernel(const RtDevScene S, const
     planes[2 * RT_TILE_PIXELS] = (uint16_t)b;
 }
 
+// ---- end of a batch's issued rounds: tell the host whether anybody is still waiting ------------------------------------------
+// One workgroup.  The main queue slices of round `round` (what logic(round - 1) appended) hold one request per path that is not
+// finished; their sum goes to the mapped host word, so the host can issue a frame's rounds without looking at the queue in
+// between and check afterwards (rt_api.cpp).
+__global__ __launch_bounds__(256) void wf_status_kernel(const RtWavefront W, const uint32_t round)
+{
+    __shared__ uint32_t part[4];
+    uint32_t n = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x]; // RT_WF_SHARDS == 256 main slices
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t waiting = part[0] + part[1] + part[2] + part[3];
+        if (waiting) atomicAdd(W.hostStatus + RT_WF_STATUS_WAITING, waiting);
+        atomicAdd(W.hostStatus + RT_WF_STATUS_BATCHES, 1u);
+    }
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------------------------
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream)
 {
@@ -1300,9 +1313,16 @@ extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront
 }
 
 // one workgroup per 256 sorted entries (grid sized for the worst case; surplus workgroups exit at once)
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t blocks, hipStream_t stream)
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf);
+    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtw_launch_status(const RtWavefront *wf, uint32_t round, hipStream_t stream)
+{
+    static_assert(RT_WF_SHARDS == 256, "wf_status_kernel sums one main queue slice per thread");
+    hipLaunchKernelGGL(wf_status_kernel, dim3(1), dim3(256), 0, stream, *wf, round);
     return hipGetLastError();
 }
 

@@ -62,7 +62,7 @@ DROPIN_SYMBOLS = [
     "dot", "cross", "normalize", "vector", "bindf", "GetPointToLineSqLen", "RayIntersectsTriangle", "GetBoxAddress",
 ]
 RESIDENT_SYMBOLS = [
-    "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles",
+    "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
     L.rtHipSceneBytes.restype = u64
     L.rtHipSceneBytes.argtypes = [vp]
     L.rtHipRenderTiles.argtypes = [vp, vp]
+    L.rtHipFrameFinish.argtypes = [vp, C.POINTER(C.c_int)]
     L.rtHipRenderTilesCounted.argtypes = [vp, C.POINTER(Stats)]
     L.rtHipDebugCounters.argtypes = [vp, C.POINTER(C.c_uint64 * 8), C.c_int]
     L.rtHipSetPipeline.argtypes = [vp, C.c_int]
@@ -339,6 +340,13 @@ class ResidentScene:
 
     def render(self, stream: int = 0):
         self._check(lib().rtHipRenderTiles(self.handle, stream or None), "rtHipRenderTiles")
+
+    def finish(self) -> bool:
+        """After the caller's own synchronisation: checks that the frames issued since the last check were complete
+        (rtHipFrameFinish).  Returns True when the last frame had to be rendered again (its launch plan was too short)."""
+        redone = C.c_int(0)
+        self._check(lib().rtHipFrameFinish(self.handle, C.byref(redone)), "rtHipFrameFinish")
+        return bool(redone.value)
 
     def set_pipeline(self, pipeline: int):
         self._check(lib().rtHipSetPipeline(self.handle, pipeline), "rtHipSetPipeline")

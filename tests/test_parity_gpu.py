@@ -329,3 +329,56 @@ def test_baseline_config5_4k_10m():
     16th row against the oracle (0.06 M rays/s per core at this size)."""
     sc = _bench_scene("lambert_10m_4k")
     _assert_sampled_rows(sc, R.render_resident(sc, 0), 16, "3840x2160 / 10 M")
+
+
+def test_planned_frames_and_a_plan_that_is_too_short(monkeypatch):
+    """Frames after a scene's first are issued from a launch plan without any host synchronisation and verified afterwards
+    (rtHipFrameFinish).  (1) Planned frames give the same planes as the watched first frame.  (2) With the plan cut to one round
+    (RT_WF_PLAN_ROUNDS=1, a test hook) a planned frame is incomplete: finish() must notice, render the frame again and say so."""
+    sc, want = load_golden_scene("mirror_hall")  # many rounds
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()                      # discovery frame (watched)
+        assert not rs.finish()
+        for _ in range(3):
+            rs.render()                  # planned frames
+        assert_planes(rs.readback(), want, "planned frame")
+        assert not rs.finish()
+        rs.stage_timing(True)
+        rs.render()
+        rs.sync()
+        _, rounds = rs.stage_times_ms()
+        assert rounds >= 4               # mirrors: the plan covers all of them
+    finally:
+        rs.close()
+    monkeypatch.setenv("RT_WF_PLAN_ROUNDS", "1")
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        assert not rs.finish()           # the first frame is always watched
+        rs.render()                      # one planned round only: paths are still waiting
+        rs.sync(0)
+        # sync() has already redone the frame; a second planned frame checked through finish() reports it
+        rs.render()
+        assert rs.finish() is True
+        assert_planes(rs.readback(), want, "frame redone after a too-short plan")
+    finally:
+        rs.close()
+
+
+def test_primary_only_frames_issue_no_empty_rounds():
+    """BASELINE config 2 (luminance-only material, no lights): no path ever waits for the grid, so the plan of a later frame is
+    primary + one logic round -- no sort / trace launches at all."""
+    sc, want = load_golden_scene("primary_only")
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        rs.sync()
+        rs.stage_timing(True)
+        rs.render()
+        rs.sync()
+        ms, rounds = rs.stage_times_ms()
+        assert rounds == 1 and ms["trace"] == 0.0 and ms["sort"] == 0.0 and ms["primary"] > 0 and ms["logic"] > 0
+        assert_planes(rs.readback(), want, "primary_only, planned frame")
+    finally:
+        rs.close()
