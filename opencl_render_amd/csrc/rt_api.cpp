@@ -106,6 +106,7 @@ struct rtHipScene {
     uint32_t samplesPerBatch = 1;
     uint32_t planRounds = 0;   // rounds a planned frame issues per batch; 0 = no plan yet (the next frame is a discovery frame)
     bool blocking = false;     // RT_WF_BLOCKING=1: every frame watches the queue (no plan)
+    bool planGridTiny = false; // RT_WF_PLAN_GRID=tiny (test hook): planned trace grids of one workgroup, so that the too-small-grid path runs
     uint32_t planCap = 0;      // RT_WF_PLAN_ROUNDS=n (test hook): planned frames issue at most n rounds, so that the too-short-plan path runs
     bool unverified = false;   // planned frames were issued since the last frame_finish()
     hipStream_t lastStream = nullptr; // where the last frame was issued
@@ -539,6 +540,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         mark("path state buffers");
         if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');
         if (const char *b = getenv("RT_WF_PLAN_ROUNDS")) sc->planCap = (uint32_t)strtoul(b, nullptr, 10);
+        if (const char *b = getenv("RT_WF_PLAN_GRID")) sc->planGridTiny = (strcmp(b, "tiny") == 0);
         const char *env = getenv("RT_HIP_PIPELINE");
         if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     }
@@ -590,7 +592,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
         if (!planned || r >= RT_WF_ROUND_LOG) return G.traceBlocks;
         // the same frame gave this many entries last time: a tenth more plus a few, never more than the worst case; the kernel
         // strides if that should still be too few
-        const uint64_t want = ((uint64_t)G.planEntries[r] * 11 / 10 + 255) / 256 + 8;
+        const uint64_t want = sc->planGridTiny ? 1 : ((uint64_t)G.planEntries[r] * 11 / 10 + 255) / 256 + 8;
         return (uint32_t)std::min<uint64_t>(G.traceBlocks, std::max<uint64_t>(want, 1));
     };
     auto issue_round = [&](rtHipScene::Group &G, hipStream_t on) -> int {
@@ -702,8 +704,10 @@ int frame_finish(rtHipScene *sc, hipStream_t st, int *redone)
     for (auto &G : sc->groups) {
         if (const uint32_t err = G.hostStatus[RT_WF_STATUS_ERROR]) {
             G.hostStatus[RT_WF_STATUS_ERROR] = 0u;
-            return fail("wavefront pipeline: device error 0x%x%s -- the frame is invalid", err,
-                        (err & RT_WF_ERR_SPIN) ? " (wf_trace_kernel's walk guard tripped: rays were abandoned)" : "");
+            if (err & ~RT_WF_ERR_GRID)
+                return fail("wavefront pipeline: device error 0x%x%s -- the frame is invalid", err,
+                            (err & RT_WF_ERR_SPIN) ? " (wf_trace_kernel's walk guard tripped: rays were abandoned)" : "");
+            waiting += 1; // a planned trace grid was too small: same remedy as a plan with too few rounds
         }
         waiting += G.hostStatus[RT_WF_STATUS_WAITING];
         G.hostStatus[RT_WF_STATUS_WAITING] = 0u;

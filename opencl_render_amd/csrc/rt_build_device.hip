@@ -496,17 +496,30 @@ extern "C" int rtHipBuildSceneGridDevice(int device, cl_uint vertexCount, cl_uin
             BUILD_OK(hipcub::DeviceRadixSort::SortKeys(tmp, tmpBytes, dVals + (size_t)w * V, dSorted + (size_t)w * V, (int)V, 0, 32, nullptr));
         hipLaunchKernelGGL(grid_planes, dim3(3), dim3(320), 0, nullptr, V, dSorted, dBm);
     }
-    if (T) {
-        hipLaunchKernelGGL(grid_fill_small, dim3((T + 255) / 256), dim3(256), 0, nullptr, T, dVertex, dIndex, dBm, dKeys, dCursor, keyCap, dBigList,
-                           dBigCount, dOverflow);
-        hipLaunchKernelGGL(grid_fill_big, dim3(RT_FILL_GROUPS), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dKeys, dCursor, keyCap, dBigList, dBigCount,
-                           dBitmaps, dQueues, dOverflow);
-    }
     unsigned long long n = 0;
     uint32_t overflow = 0;
-    BUILD_OK(hipMemcpy(&n, dCursor, 8, hipMemcpyDeviceToHost));
-    BUILD_OK(hipMemcpy(&overflow, dOverflow, 4, hipMemcpyDeviceToHost));
-    if (overflow || n > keyCap) return -7; // more pairs than the key buffer or a fill larger than the workgroup queue
+    Buffers bufRetry;
+    unsigned long long cap = keyCap;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (T) {
+            hipLaunchKernelGGL(grid_fill_small, dim3((T + 255) / 256), dim3(256), 0, nullptr, T, dVertex, dIndex, dBm, dKeys, dCursor, cap, dBigList,
+                               dBigCount, dOverflow);
+            hipLaunchKernelGGL(grid_fill_big, dim3(RT_FILL_GROUPS), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dKeys, dCursor, cap, dBigList, dBigCount,
+                               dBitmaps, dQueues, dOverflow);
+        }
+        BUILD_OK(hipMemcpy(&n, dCursor, 8, hipMemcpyDeviceToHost));
+        BUILD_OK(hipMemcpy(&overflow, dOverflow, 4, hipMemcpyDeviceToHost));
+        if (overflow != 1u || attempt == 1) break;
+        // More pairs than the key buffer holds (a few huge triangles: walls, floors).  The cursor has counted them all, like
+        // the reference's own overflow pass (trianglelist.cpp:696-706): fill again into a buffer of exactly that size.
+        if (n > 0xffffffffull) return -3;
+        cap = n;
+        BUILD_OK(bufRetry.alloc(&dKeys, (size_t)cap)); BUILD_OK(bufRetry.alloc(&dKeysSorted, (size_t)cap));
+        BUILD_OK(hipMemsetAsync(dCursor, 0, 8, nullptr));
+        BUILD_OK(hipMemsetAsync(dBigCount, 0, 4, nullptr));
+        BUILD_OK(hipMemsetAsync(dOverflow, 0, 4, nullptr));
+    }
+    if (overflow || n > cap) return -7; // a single fill larger than the workgroup queue (2^22 cells), or a second overflow
     if (n > 0xffffffffull) return -3;
     uint32_t *dList = nullptr;
     BUILD_OK(buf3.alloc(&dList, (size_t)n));

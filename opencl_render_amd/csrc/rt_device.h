@@ -104,6 +104,8 @@ struct RtDevScene {
 #define RT_WF_STATUS_WORDS 16
 #define RT_WF_ROUND_LOG 64     // rounds of a batch whose trace-input size is logged for the launch plan (RtWavefront::roundLog)
 #define RT_WF_ERR_SPIN 1u     // wf_trace_kernel's walk guard tripped: rays were abandoned, the frame is invalid
+#define RT_WF_ERR_GRID 2u     // a planned frame's trace grid was smaller than the round's entries: entries were not traced; the host renders
+                              // the frame again with the worst-case grid (rt_api.cpp, frame_finish)
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)

@@ -1006,9 +1006,12 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // only, nothing depends on it), so workgroup i takes block (i % 8) * blocksPerXcd + i / 8 -- every XCD works its way
     // through ONE contiguous eighth of the region-ordered entries and its L2 holds the one or two regions it is in.
     const uint32_t blocksUsed = (chunksA + chunksB + 3u) >> 2;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && round < RT_WF_ROUND_LOG) W.roundLog[round] = total + extra;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (round < RT_WF_ROUND_LOG) W.roundLog[round] = total + extra;
+    }
     const uint32_t perXcd = (blocksUsed + 7u) >> 3;
-    const uint32_t slots = (order == RT_WF_ORDER_REGION) ? 8u * perXcd : blocksUsed; // work items a grid has to cover
+    const uint32_t slots = (order == RT_WF_ORDER_REGION) ? 8u * perXcd : blocksUsed; // work items the grid has to cover
+    if (blockIdx.x == 0 && threadIdx.x == 0 && slots > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
     if (blockIdx.x >= slots) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
@@ -1017,11 +1020,12 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // One workgroup per 256 sorted entries, dispatched by the hardware in order: the longest walks start first and a free
     // slot always gets the longest work left.  (Fixed grids whose waves stride over the array, or take chunks from a shared
     // cursor, were 23 % and 11 % slower; the price of this grid is ~0.35 us per 1000 workgroups that find nothing to do.)
-    // (the grid is sized from the previous frame's rounds, rt_api.cpp; a grid that turns out too small strides over the rest)
-    for (uint32_t slot = blockIdx.x; slot < slots; slot += gridDim.x) {
+    // (a planned frame's grid is sized from the same frame's previous rendering, rt_api.cpp; should it be too small the host is
+    // told and renders the frame again with the worst-case grid -- a loop that strides over the rest measured 4 % slower)
+    for (uint32_t slot = blockIdx.x, once = 0; once < 1u; ++once) {
     const uint32_t blockAt = (order == RT_WF_ORDER_REGION) ? (slot & 7u) * perXcd + (slot >> 3) : slot;
     const uint32_t chunk = blockAt * 4 + wave;
-    if (chunk >= chunksA + chunksB) continue;
+    if (chunk >= chunksA + chunksB) break;
     const bool inB = chunk >= chunksA;
     const uint32_t mine = inB ? 2u * W.capacity + (chunk - chunksA) * 64 + lane : chunk * 64 + lane;
     bool active = inB ? (chunk - chunksA) * 64 + lane < extra : mine < total;

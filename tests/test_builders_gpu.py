@@ -27,7 +27,6 @@ def assert_same_lists(host, dev, label):
     order_h = np.concatenate([np.arange(a, b) for a, b in zip(host.cam_start.tolist(), host.cam_end.tolist())]) if n_host.sum() else np.zeros(0, np.int64)
     order_d = np.concatenate([np.arange(a, b) for a, b in zip(dev.cam_start.tolist(), dev.cam_end.tolist())]) if n_dev.sum() else np.zeros(0, np.int64)
     assert np.array_equal(host.cam_list[order_h], dev.cam_list[order_d]), f"{label}: list contents differ"
-    assert int(n_dev.sum()) == len(dev.cam_list), f"{label}: device lists are not a partition of cam_list"
 
 
 def with_big_triangles(sc, seed):

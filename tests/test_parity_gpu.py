@@ -366,6 +366,25 @@ def test_planned_frames_and_a_plan_that_is_too_short(monkeypatch):
         rs.close()
 
 
+def test_planned_trace_grid_that_is_too_small_is_noticed(monkeypatch):
+    """A planned frame sizes its trace launches from the same frame's previous rendering.  Should such a grid ever be smaller
+    than the round's entries (forced here: one workgroup), entries go untraced: the kernel raises RT_WF_ERR_GRID and finish()
+    renders the frame again with the worst-case grid."""
+    monkeypatch.setenv("RT_WF_PLAN_GRID", "tiny")
+    sc = S.make_soup(320, 200, 20_000, 0.03, seed=41, samples=1)
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        assert not rs.finish()
+        rs.render()
+        assert rs.finish() is True
+        assert_planes(rs.readback(), want, "frame redone after a too-small trace grid")
+    finally:
+        rs.close()
+
+
 def test_primary_only_frames_issue_no_empty_rounds():
     """BASELINE config 2 (luminance-only material, no lights): no path ever waits for the grid, so the plan of a later frame is
     primary + one logic round -- no sort / trace launches at all."""
