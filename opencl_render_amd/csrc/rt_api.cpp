@@ -30,6 +30,14 @@ extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t
 extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
                                         uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream);
 
+extern "C" hipError_t rtp_validate(uint32_t T, uint32_t V, uint32_t M, const void *triIndex, const int *triMaterial, uint64_t camListSize,
+                                   const uint32_t *camList, const uint32_t *gridStart, uint64_t gridListSize, const uint32_t *gridList, uint32_t *err,
+                                   hipStream_t stream);
+extern "C" hipError_t rtp_camera_ranges(uint32_t W, uint32_t H, uint32_t tilesX, const uint32_t *tileIds, uint32_t tileCount, const uint32_t *camStart,
+                                        const uint32_t *camEnd, uint64_t camListSize, uint32_t *outStart, uint32_t *outEnd, uint32_t *err, hipStream_t stream);
+extern "C" hipError_t rtp_dense_grid(const uint32_t *gridStart, const uint32_t *gridList, unsigned long long *words, uint32_t *sparse, uint32_t *pairOrder,
+                                     uint32_t *pairCount, uint32_t *cellRest, void *scratch, size_t *scratchBytes, hipStream_t stream);
+
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
@@ -70,13 +78,87 @@ struct DevScratch {
     }
 };
 
+// Host-to-device copies go through two pinned buffers (hipHostMalloc once per scene, RT_HIP_STAGE_MB each, default 32): the
+// caller's arrays are pageable (new[] in render.cpp:1089-1123), and a pageable hipMemcpy is a synchronous bounce through the
+// runtime's own small staging area.  Here the CPU fills one buffer (several threads for big pieces) while the DMA engine
+// drains the other; copy() returns when the source has been read completely, so callers may free it at once.
+struct Stager {
+    hipStream_t stream = nullptr;
+    char *buf[2] = { nullptr, nullptr };
+    hipEvent_t done[2] = { nullptr, nullptr };
+    bool used[2] = { false, false };
+    size_t size = 0;
+    int next = 0;
+    int init(hipStream_t st)
+    {
+        stream = st;
+        size = (size_t)32 << 20;
+        if (const char *b = getenv("RT_HIP_STAGE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 4096) size = (size_t)v << 20; }
+        for (int i = 0; i < 2; ++i) {
+            HIP_OK(hipHostMalloc((void **)&buf[i], size, hipHostMallocDefault));
+            HIP_OK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        return 0;
+    }
+    static void fill(char *dst, const char *src, size_t n)
+    {
+        const size_t piece = (size_t)4 << 20;
+        if (n < 2 * piece) { memcpy(dst, src, n); return; }
+        const size_t parts = std::min<size_t>(8, n / piece);
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < parts; ++t) pool.emplace_back([=] { memcpy(dst + n * t / parts, src + n * t / parts, n * (t + 1) / parts - n * t / parts); });
+        memcpy(dst, src, n / parts);
+        for (auto &th : pool) th.join();
+    }
+    hipError_t copy(void *dst, const void *src, size_t bytes)
+    {
+        for (size_t off = 0; off < bytes;) {
+            const size_t n = std::min(size, bytes - off);
+            const int i = next;
+            next ^= 1;
+            if (used[i]) { const hipError_t e = hipEventSynchronize(done[i]); if (e != hipSuccess) return e; }
+            fill(buf[i], (const char *)src + off, n);
+            hipError_t e = hipMemcpyAsync((char *)dst + off, buf[i], n, hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+            e = hipEventRecord(done[i], stream);
+            if (e != hipSuccess) return e;
+            used[i] = true;
+            off += n;
+        }
+        return hipSuccess;
+    }
+    hipError_t drain()
+    {
+        for (int i = 0; i < 2; ++i)
+            if (used[i]) { const hipError_t e = hipEventSynchronize(done[i]); if (e != hipSuccess) return e; used[i] = false; }
+        return hipSuccess;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (done[i]) { if (used[i]) (void)hipEventSynchronize(done[i]); (void)hipEventDestroy(done[i]); done[i] = nullptr; }
+            if (buf[i]) { (void)hipHostFree(buf[i]); buf[i] = nullptr; }
+        }
+    }
+};
+
+enum { PART_FIXED = 0, PART_CAMERA, PART_GEOMETRY, PART_GRID, PART_MATERIALS, PART_LIGHTS, PART_WAVEFRONT, PART_COUNT };
+
 } // namespace
 
 struct rtHipScene {
     int device = -1;
     hipStream_t stream = nullptr;
     RtDevScene dev{};
-    std::vector<void *> allocs;
+    // Device allocations by PART (tiles + outputs | camera lists | geometry | grid | materials | lights | path state): the drop-in
+    // layer's cache replaces the parts whose inputs changed between two RaytraceAll calls and keeps the others in HBM.
+    std::vector<void *> partAllocs[PART_COUNT];
+    uint64_t partBytes[PART_COUNT] = { 0 };
+    int curPart = PART_FIXED;
+    Stager stager;
+    uint32_t *prepErr = nullptr;   // device word: RT_PREP_ERR_* bits raised by the validation kernels
+    uint64_t camListSize = 0;
+    bool wfMultiLight = false;     // what the path-state buffers were sized for
     uint64_t bytes = 0;
     std::vector<cl_uint> tileIds;
     uint32_t width = 0, height = 0, tilesX = 0;
@@ -97,6 +179,7 @@ struct rtHipScene {
         uint32_t *hostCount = nullptr;  // pinned: queue length read back between round chunks
         uint32_t *hostStatus = nullptr; // pinned + mapped: RT_WF_STATUS_* words the kernels write (rt_device.h)
         uint32_t rounds = 0;
+        uint32_t slot0 = 0, slot1 = 0;  // this group's range of the instance's tile slots
         // launch plan (render_wavefront): what the last discovery frame needed
         uint32_t roundsNeeded = 0;
         uint32_t planEntries[RT_WF_ROUND_LOG] = { 0 }, planEntriesNext[RT_WF_ROUND_LOG] = { 0 };
@@ -122,11 +205,12 @@ struct rtHipScene {
         void *p = nullptr;
         const uint64_t n = count ? count : 1;
         HIP_OK(hipMalloc(&p, n * sizeof(T)));
-        allocs.push_back(p);
+        partAllocs[curPart].push_back(p);
+        partBytes[curPart] += n * sizeof(T);
         bytes += n * sizeof(T);
         if (count) {
             if (!src) return fail("%s: null pointer with %llu elements", what, (unsigned long long)count);
-            HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+            HIP_OK(stager.copy(p, src, count * sizeof(T)));
         }
         *dst = (const T *)p;
         return 0;
@@ -136,35 +220,46 @@ struct rtHipScene {
         void *p = nullptr;
         const uint64_t n = count ? count : 1;
         HIP_OK(hipMalloc(&p, n * sizeof(T)));
-        allocs.push_back(p);
+        partAllocs[curPart].push_back(p);
+        partBytes[curPart] += n * sizeof(T);
         bytes += n * sizeof(T);
         *dst = (T *)p;
         return 0;
+    }
+    void release_part(int part)
+    {
+        if (partAllocs[part].empty()) return;
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (void *p : partAllocs[part]) (void)hipFree(p);
+        partAllocs[part].clear();
+        bytes -= partBytes[part];
+        partBytes[part] = 0;
+    }
+    // looks at the device-side validation word (after the caller's stream synchronisation)
+    int check_prep()
+    {
+        uint32_t err = 0;
+        HIP_OK(hipMemcpy(&err, prepErr, 4, hipMemcpyDeviceToHost));
+        if (!err) return 0;
+        HIP_OK(hipMemset(prepErr, 0, 4));
+        return fail("scene rejected (0x%x):%s%s%s%s%s%s", err,
+                    (err & RT_PREP_ERR_TRI_INDEX) ? " a triangle references a vertex that does not exist;" : "",
+                    (err & RT_PREP_ERR_TRI_MATERIAL) ? " a triangle uses a material >= materialCount;" : "",
+                    (err & RT_PREP_ERR_CAM_ENTRY) ? " a camera list entry is not a triangle;" : "",
+                    (err & RT_PREP_ERR_CAM_RANGE) ? " a camera list range exceeds the list size;" : "",
+                    (err & RT_PREP_ERR_GRID_MONOTONE) ? " scenePixelTriangleListStart is not monotone;" : "",
+                    (err & RT_PREP_ERR_GRID_ENTRY) ? " a grid list entry is not a triangle;" : "");
     }
 };
 
 namespace {
 
-int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds, cl_uint tileCount)
+// ---- scene parts -------------------------------------------------------------------------------------------------------
+// A resident scene is built in PARTS with their own device allocations, so that the drop-in layer's cache (RaytraceAll
+// below) can replace what changed between two calls -- typically the camera -- and keep the rest in HBM.
+int build_fixed(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds, cl_uint tileCount)
 {
-    if (!d) return fail("null scene description");
-    if (d->width == 0 || d->height == 0) return fail("empty image %ux%u", d->width, d->height);
-    if (d->sampleCount == 0) return fail("sampleCount must be >= 1");
-    if (d->axesDiv != RT_GRID_DIV) return fail("axesDivCount %d unsupported (the reference builds %d, trianglelist.h:110)", d->axesDiv, RT_GRID_DIV);
-    if ((uint64_t)d->width * d->height > 0xffffffffull) return fail("image too large");
-    HIP_OK(hipSetDevice(sc->device));
-    HIP_OK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
-    // RT_HIP_TIMING=1: where the time of a scene upload goes (stderr)
-    const bool timing = getenv("RT_HIP_TIMING") != nullptr;
-    auto tLast = std::chrono::steady_clock::now();
-    auto mark = [&](const char *what) {
-        if (!timing) return;
-        (void)hipStreamSynchronize(sc->stream);
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "libraytrace_hip: scene build: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tLast).count());
-        tLast = now;
-    };
-
+    sc->curPart = PART_FIXED;
     const uint32_t tilesX = (d->width + RT_TILE - 1) / RT_TILE, tilesY = (d->height + RT_TILE - 1) / RT_TILE;
     sc->width = d->width; sc->height = d->height; sc->tilesX = tilesX;
     const bool allTiles = (tileIds == nullptr || tileCount == 0);
@@ -177,373 +272,374 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
             if (t >= tilesX * tilesY) return fail("tile id %u out of range (%u tiles)", t, tilesX * tilesY);
     }
     const uint32_t nt = (uint32_t)sc->tileIds.size();
+    RtDevScene &D = sc->dev;
+    D.width = d->width; D.height = d->height;
+    D.tileCount = nt; D.tilesX = tilesX;
+    const cl_uint *ids = nullptr;
+    if (sc->upload(sc->tileIds.data(), nt, &ids, "tileIds")) return -1;
+    D.tileIds = ids;
+    uint16_t *buf = nullptr;
+    if (sc->alloc<uint16_t>((uint64_t)nt * 3 * RT_TILE_PIXELS, &buf)) return -1;
+    HIP_OK(hipMemsetAsync(buf, 0, (uint64_t)nt * 3 * RT_TILE_PIXELS * 2, sc->stream));
+    D.tileBuf = buf;
+    unsigned long long *st = nullptr;
+    if (sc->alloc<unsigned long long>(8, &st)) return -1;
+    HIP_OK(hipMemsetAsync(st, 0, 64, sc->stream));
+    D.stats = st;
+    if (sc->alloc<uint32_t>(1, &sc->prepErr)) return -1;
+    HIP_OK(hipMemsetAsync(sc->prepErr, 0, 4, sc->stream));
+    // bump: xPart/yPart = (float)sin(dh*PI_F/2.f), normalPart factors = (float)cos(...) (raytrace_opencl.c:251-253) with
+    // dh = hE/255.f - h0/255.f.  Only 256x256 byte pairs exist: tabulate with the HOST libm -- the library the reference's
+    // C path calls -- so the device result is that library's, bit for bit.
+    std::vector<float> tsin(65536), tcos(65536);
+    for (int e = 0; e < 256; ++e)
+        for (int h = 0; h < 256; ++h) {
+            const float fe = (float)e / 255.f, fh = (float)h / 255.f;
+            const float arg = (fe - fh) * 3.14159265f / 2.f;
+            tsin[(e << 8) | h] = (float)std::sin((double)arg);
+            tcos[(e << 8) | h] = (float)std::cos((double)arg);
+        }
+    if (sc->upload(tsin.data(), tsin.size(), &D.bumpSin, "bumpSin")) return -1;
+    if (sc->upload(tcos.data(), tcos.size(), &D.bumpCos, "bumpCos")) return -1;
+    HIP_OK(sc->stager.drain());
+    return 0;
+}
 
+// camera vectors + the per-pixel candidate lists: uploaded as they are, the tile-major view of this instance's tiles is made
+// on the device (rt_scene_prep.hip)
+int build_camera(rtHipScene *sc, const rtHipSceneDesc *d)
+{
+    sc->release_part(PART_CAMERA);
+    sc->curPart = PART_CAMERA;
     RtDevScene &D = sc->dev;
     for (int i = 0; i < 3; ++i) { D.eye[i] = d->eye[i]; D.topLeft[i] = d->eyeToTopLeft[i]; D.lr[i] = d->leftToRight[i]; D.tb[i] = d->topToBottom[i]; }
     D.pixelSizeInv = d->pixelSizeInv;
-    D.width = d->width; D.height = d->height; D.sampleCount = d->sampleCount;
-    D.tileCount = nt; D.tilesX = tilesX;
+    const uint64_t P = (uint64_t)d->width * d->height;
+    if (!d->camStart || !d->camEnd) return fail("null cameraPixelTriangleListStart/End");
+    if (d->camListSize && !d->camList) return fail("null cameraPixelTriangleList");
+    if (d->camListSize > 0xffffffffull) return fail("camera list too large");
+    const cl_uint *srcStart = nullptr, *srcEnd = nullptr;
+    DevScratch scratch; // the row-major ranges are only needed until the tile-major ones exist
+    void *p0 = nullptr, *p1 = nullptr;
+    HIP_OK(scratch.get(&p0, P * 4)); HIP_OK(scratch.get(&p1, P * 4));
+    HIP_OK(sc->stager.copy(p0, d->camStart, P * 4));
+    HIP_OK(sc->stager.copy(p1, d->camEnd, P * 4));
+    srcStart = (const cl_uint *)p0; srcEnd = (const cl_uint *)p1;
+    if (sc->upload(d->camList, d->camListSize, &D.camList, "camList")) return -1;
+    sc->camListSize = d->camListSize;
+    uint32_t *ts = nullptr, *te = nullptr;
+    const uint64_t n = (uint64_t)D.tileCount * RT_TILE_PIXELS;
+    if (sc->alloc<uint32_t>(n, &ts) || sc->alloc<uint32_t>(n, &te)) return -1;
+    HIP_OK(rtp_camera_ranges(d->width, d->height, D.tilesX, D.tileIds, D.tileCount, srcStart, srcEnd, d->camListSize, ts, te, sc->prepErr, sc->stream));
+    D.camStart = ts; D.camEnd = te;
+    HIP_OK(hipStreamSynchronize(sc->stream)); // scratch dies here
+    return 0;
+}
+
+// geometry: upload the ABI arrays, reshape on the device (rt_prepare_triangles), drop the originals
+int build_geometry(rtHipScene *sc, const rtHipSceneDesc *d)
+{
+    sc->release_part(PART_GEOMETRY);
+    sc->curPart = PART_GEOMETRY;
+    RtDevScene &D = sc->dev;
     D.triangleCount = d->triangleCount;
+    if (d->triangleCount && (!d->triIndex || !d->triMaterial || !d->triUv || !d->triNormal)) return fail("null triangle array");
+    if (d->vertexCount && !d->vertex) return fail("null vertex array");
+    void *dv = nullptr, *di = nullptr, *dm = nullptr, *du = nullptr, *dn = nullptr;
+    const uint64_t T = d->triangleCount, V = d->vertexCount;
+    DevScratch scratch;
+    HIP_OK(scratch.get(&dv, V * 16)); HIP_OK(scratch.get(&di, T * 16)); HIP_OK(scratch.get(&dm, T * 4));
+    HIP_OK(scratch.get(&du, T * 24)); HIP_OK(scratch.get(&dn, T * 48));
+    HIP_OK(sc->stager.copy(dv, d->vertex, V * 16));
+    HIP_OK(sc->stager.copy(di, d->triIndex, T * 16));
+    HIP_OK(sc->stager.copy(dm, d->triMaterial, T * 4));
+    HIP_OK(sc->stager.copy(du, d->triUv, T * 24));
+    HIP_OK(sc->stager.copy(dn, d->triNormal, T * 48));
+    float *rec = nullptr, *shade = nullptr;
+    if (sc->alloc<float>(T * 16, &rec) || sc->alloc<float>(T * 24, &shade)) return -1;
+    // ids are checked on the device before anything gathers through them; a scene with a bad id fails at the end of the build
+    HIP_OK(rtp_validate(d->triangleCount, d->vertexCount, d->materialCount, di, (const int *)dm, 0, nullptr, nullptr, 0, nullptr, sc->prepErr, sc->stream));
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    if (sc->check_prep() != 0) return -1; // rt_prepare_triangles would gather out of bounds
+    HIP_OK(rtk_launch_prepare(d->triangleCount, dv, di, dm, du, dn, rec, shade, sc->stream));
+    D.triRec = rec; D.triShade = shade;
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    return 0;
+}
 
-    // --- per-pixel candidate lists, re-ordered tile-major; only this instance's tiles are shipped -------------
+// the grid as the ABI hands it over, plus its dense view for the wavefront trace kernel, built on the device
+int build_grid(rtHipScene *sc, const rtHipSceneDesc *d)
+{
+    sc->release_part(PART_GRID);
+    sc->curPart = PART_GRID;
+    RtDevScene &D = sc->dev;
+    if (!d->boxMin) return fail("null sceneBoxMin");
+    std::vector<float> planes(3 * (RT_GRID_DIV + 1));
+    for (int w = 0; w < 3; ++w)
+        for (int i = 0; i <= RT_GRID_DIV; ++i) planes[w * (RT_GRID_DIV + 1) + i] = d->boxMin[i].s[w];
+    if (sc->upload(planes.data(), planes.size(), &D.boxMin, "boxMin")) return -1;
+    const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
+    if (!d->gridStart) return fail("null scenePixelTriangleListStart");
+    const uint64_t listSize = d->gridStart[cells];
+    if (listSize && !d->gridList) return fail("null scenePixelTriangleList");
+    if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
+    if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
+    // (the triangle count the entries are checked against is this scene's: geometry is built before the grid)
+    HIP_OK(rtp_validate(D.triangleCount, 0, 0, nullptr, nullptr, 0, nullptr, D.gridStart, listSize, D.gridList, sc->prepErr, sc->stream));
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    if (sc->check_prep() != 0) return -1; // the dense view walks the lists through the starts
+    const size_t blocks = (size_t)(RT_GRID_DIV / 4) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4);
+    unsigned long long *words = nullptr;
+    uint32_t *sparse = nullptr, *cellRest = nullptr;
+    const size_t sparseWords = (size_t)3 * ((63u << 16 | 63u << 8 | 63u) + 1u);
+    if (sc->alloc<unsigned long long>(blocks, &words) || sc->alloc<uint32_t>(sparseWords, &sparse) ||
+        sc->alloc<uint32_t>(std::min<uint64_t>(listSize, cells), &cellRest))
+        return -1;
+    HIP_OK(hipMemsetAsync(sparse, 0, sparseWords * 4, sc->stream));
+    DevScratch scratch;
+    uint32_t *pairOrder = nullptr, *pairCount = nullptr;
+    void *tmp = nullptr;
+    size_t tmpBytes = 0;
+    HIP_OK(rtp_dense_grid(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tmpBytes, sc->stream));
+    HIP_OK(scratch.get((void **)&pairOrder, (size_t)listSize * 4)); HIP_OK(scratch.get((void **)&pairCount, (size_t)listSize * 4));
+    HIP_OK(scratch.get(&tmp, tmpBytes));
+    HIP_OK(rtp_dense_grid(D.gridStart, D.gridList, words, sparse, pairOrder, pairCount, cellRest, tmp, &tmpBytes, sc->stream));
+    float *pairRec = nullptr;
+    if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
+    HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, pairOrder, pairCount, D.triRec, pairRec, sc->stream));
+    D.gridBits = words; D.gridBlockSparse = sparse; D.cellRest = cellRest; D.pairRec = pairRec;
+    D.cellCount = 0; // informational; the kernels find a cell's records through the block table
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    return 0;
+}
+
+int build_materials(rtHipScene *sc, const rtHipSceneDesc *d)
+{
+    sc->release_part(PART_MATERIALS);
+    sc->curPart = PART_MATERIALS;
+    RtDevScene &D = sc->dev;
+    D.materialCount = d->materialCount;
+    D.texelCount = d->texturesSize ? d->texturesSize : 1;
+    if (sc->upload((const uint32_t *)d->matSize, (uint64_t)d->materialCount * 10, &D.matSize, "materialImageSize")) return -1;
+    if (sc->upload((const int32_t *)d->matStart, (uint64_t)d->materialCount * 5, &D.matStart, "materialImageStart")) return -1;
+    if (sc->upload((const uint8_t *)d->textures, (uint64_t)d->texturesSize * 4, &D.textures, "textures")) return -1;
+    for (uint32_t m = 0; m < d->materialCount * 5; ++m) {
+        const uint64_t w = d->matSize[m].s[0], h = d->matSize[m].s[1];
+        if (w && ((int64_t)d->matStart[m] < 0 || (uint64_t)d->matStart[m] + w * h > d->texturesSize))
+            return fail("material channel %u: %llux%llu texels at %d exceed the %u-texel atlas", m, (unsigned long long)w, (unsigned long long)h, d->matStart[m], d->texturesSize);
+    }
+    HIP_OK(sc->stager.drain());
+    return 0;
+}
+
+int build_lights(rtHipScene *sc, const rtHipSceneDesc *d)
+{
+    sc->release_part(PART_LIGHTS);
+    sc->curPart = PART_LIGHTS;
+    RtDevScene &D = sc->dev;
+    if (d->lightCount >= 65536u) return fail("lightCount %u too large", d->lightCount);
+    D.lightCount = d->lightCount;
+    std::vector<float> spread(d->lightCount ? d->lightCount : 1, 0.f);
+    for (uint32_t j = 0; j < d->lightCount; ++j) {
+        const float *ld = d->lightDir[j].s;
+        const float dd = ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2];
+        // raytrace_opencl.c:594 (double sin * double sqrt, then one rounding to float)
+        spread[j] = (float)(std::sin((double)((d->lightRadius[j] / 2.f) * 3.14159265f / 180.f)) * std::sqrt((double)dd));
+    }
+    if (sc->upload(d->lightType, d->lightCount, &D.lightType, "lightType")) return -1;
+    if (sc->upload((const float *)d->lightPos, (uint64_t)d->lightCount * 4, &D.lightPos, "lightPosition")) return -1;
+    if (sc->upload((const float *)d->lightDir, (uint64_t)d->lightCount * 4, &D.lightDir, "lightDirection")) return -1;
+    if (sc->upload((const float *)d->lightCol, (uint64_t)d->lightCount * 4, &D.lightCol, "lightColour")) return -1;
+    if (sc->upload(d->lightRadius, d->lightCount, &D.lightRadius, "lightRadius")) return -1;
+    if (sc->upload(d->lightHalfAtt, d->lightCount, &D.lightHalfAtt, "lightHalfAttenuationDistance")) return -1;
+    if (sc->upload(spread.data(), d->lightCount, &D.lightSpread, "lightSpread")) return -1;
+    HIP_OK(sc->stager.drain());
+    return 0;
+}
+
+// wavefront pipeline buffers: worst case every pixel of every sample in a batch becomes a path
+int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
+{
+    for (auto &G : sc->groups) {
+        if (G.hostCount) (void)hipHostFree(G.hostCount);
+        if (G.hostStatus) (void)hipHostFree(G.hostStatus);
+        if (G.stream) { (void)hipStreamSynchronize(G.stream); (void)hipStreamDestroy(G.stream); }
+        if (G.done) (void)hipEventDestroy(G.done);
+    }
+    sc->groups.clear();
+    sc->release_part(PART_WAVEFRONT);
+    sc->curPart = PART_WAVEFRONT;
+    RtDevScene &D = sc->dev;
+    D.sampleCount = sampleCount;
+    sc->planRounds = 0; // the next frame watches its queue again
+    sc->unverified = false;
+    const uint32_t nt = D.tileCount;
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, sc->device));
+    const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
+    // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
+    // result, staging + sorted entry
+    uint32_t extraFactor = 6; // region B of the entry arrays, in units of the path capacity: a region-cut ray has up to 9 extra entries
+    if (const char *b = getenv("RT_WF_EXTRA_FACTOR")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) extraFactor = (uint32_t)v; }
+    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 8) + 16;
+    // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
+    // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
+    uint64_t budget = 24ull << 30;
     {
-        std::vector<cl_uint> lstart((size_t)nt * RT_TILE_PIXELS, 0), lend((size_t)nt * RT_TILE_PIXELS, 0);
-        std::vector<cl_uint> compact;
-        std::unordered_map<uint64_t, cl_uint> remap; // (start,end) of an aliased range -> offset in `compact`
-        const bool slice = !allTiles;
-        for (uint32_t s = 0; s < nt; ++s) {
-            const uint32_t tx = sc->tileIds[s] % tilesX, ty = sc->tileIds[s] / tilesX;
-            for (uint32_t ly = 0; ly < RT_TILE; ++ly) {
-                const uint32_t gy = ty * RT_TILE + ly;
-                if (gy >= d->height) break;
-                for (uint32_t lx = 0; lx < RT_TILE; ++lx) {
-                    const uint32_t gx = tx * RT_TILE + lx;
-                    if (gx >= d->width) break;
-                    const uint64_t p = (uint64_t)gy * d->width + gx;
-                    cl_uint a = d->camStart[p], b = d->camEnd[p];
-                    if (b < a) b = a;
-                    if ((uint64_t)b > d->camListSize) return fail("camera list range [%u,%u) of pixel %llu exceeds list size %llu", a, b, (unsigned long long)p, (unsigned long long)d->camListSize);
-                    const size_t li = (size_t)s * RT_TILE_PIXELS + ly * RT_TILE + lx;
-                    if (!slice) { lstart[li] = a; lend[li] = b; continue; }
-                    if (a == b) { lstart[li] = lend[li] = 0; continue; }
-                    const uint64_t key = ((uint64_t)a << 32) | b;
-                    auto it = remap.find(key);
-                    cl_uint at;
-                    if (it == remap.end()) {
-                        at = (cl_uint)compact.size();
-                        compact.insert(compact.end(), d->camList + a, d->camList + b);
-                        remap.emplace(key, at);
-                    } else at = it->second;
-                    lstart[li] = at; lend[li] = at + (b - a);
-                }
-            }
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB / 3 < budget) budget = freeB / 3;
+    }
+    if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
+    uint64_t sb = budget / (perPath * (pix ? pix : 1));
+    if (sb < 1) sb = 1;
+    if (sb > sampleCount) sb = sampleCount;
+    if (sb > 65535) sb = 65535; // the primary kernel's gridDim.y
+    sc->samplesPerBatch = (uint32_t)sb;
+    uint32_t groupCount = 1; // RT_WF_GROUPS: concurrent tile groups per instance (measured: no gain once rays are cut into segments)
+    if (const char *b = getenv("RT_WF_GROUPS")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) groupCount = (uint32_t)v; }
+    if (groupCount > nt) groupCount = nt ? (uint32_t)nt : 1u;
+    uint32_t lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
+    if (const char *b = getenv("RT_WF_LOOKAHEAD")) lookAhead = (b[0] != '0') ? 1u : 0u;
+    const bool multiLight = D.lightCount > 1;
+    sc->wfMultiLight = multiLight;
+    // segment lengths by round size (rt_wavefront.hip, wf_setup_kernel); 4096 is longer than any walk = no cutting
+    uint32_t segLen[4] = { 4096u, 256u, 64u, 16u }, segRays[3] = { 700000u, 300000u, 30000u };
+    auto parse_list = [](const char *b, uint32_t *out, int n) {
+        for (int i = 0; i < n && b && *b; ++i) {
+            char *endp = nullptr;
+            const unsigned long v = strtoul(b, &endp, 10);
+            if (endp == b) break;
+            out[i] = (uint32_t)(v ? v : 1);
+            b = (*endp == ',') ? endp + 1 : endp;
         }
-        // a bad id would be an out-of-bounds gather on the device: check on the host, where it is a loop
-        for (uint64_t i = 0; i < d->camListSize; ++i)
-            if (d->camList[i] >= d->triangleCount) return fail("camera list entry %llu = %u is not a triangle (count %u)", (unsigned long long)i, d->camList[i], d->triangleCount);
-        if (sc->upload(lstart.data(), lstart.size(), &D.camStart, "camStart")) return -1;
-        if (sc->upload(lend.data(), lend.size(), &D.camEnd, "camEnd")) return -1;
-        if (slice) { if (sc->upload(compact.data(), compact.size(), &D.camList, "camList")) return -1; }
-        else if (sc->upload(d->camList, d->camListSize, &D.camList, "camList")) return -1;
-        HIP_OK(hipStreamSynchronize(sc->stream)); // staging vectors die here
+    };
+    parse_list(getenv("RT_WF_SEG"), segLen, 4);
+    parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
+    // rounds with at least this many rays are cut at region boundaries and traced region by region (rt_wavefront.hip, wf_setup_kernel)
+    uint32_t regionRays = 0xffffffffu; // off by default: measured slower than length order once a cell visit is one fabric request
+    if (const char *b = getenv("RT_WF_REGION_RAYS")) regionRays = (uint32_t)strtoul(b, nullptr, 10);
+    uint32_t spinLimit = 16384u; // a ray makes at most 766 cell visits = 96 walk phases; RT_WF_SPIN_LIMIT lowers the guard to test its error path
+    if (const char *b = getenv("RT_WF_SPIN_LIMIT")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) spinLimit = (uint32_t)v; }
+    uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
+    if (const char *b = getenv("RT_WF_APPEND_RAYS")) appendRays = (uint32_t)strtoul(b, nullptr, 10);
+    if (!sc->forkEvent) HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
+    sc->groups.resize(groupCount);
+    for (uint32_t g = 0; g < groupCount; ++g) {
+        rtHipScene::Group &G = sc->groups[g];
+        const uint32_t slot0 = (uint32_t)((uint64_t)nt * g / groupCount), slot1 = (uint32_t)((uint64_t)nt * (g + 1) / groupCount);
+        G.slot0 = slot0; G.slot1 = slot1;
+        if (g > 0) HIP_OK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+        // queue slices: the primary kernel's workgroups are dealt to the shards round-robin, 256 paths each at most
+        const uint64_t gpix = (uint64_t)(slot1 - slot0) * RT_TILE_PIXELS;
+        const uint64_t primaryBlocks = (uint64_t)(slot1 - slot0) * 64 * sb;
+        const uint64_t shardCap = ((primaryBlocks + RT_WF_SHARDS - 1) / RT_WF_SHARDS) * 256;
+        const uint64_t cap = shardCap * RT_WF_SHARDS;
+        if (cap > 0x7ffffff0ull) return fail("tile set too large for one batch");
+        RtWavefront &Wf = G.wf;
+        Wf.capacity = (uint32_t)cap;
+        Wf.shardCap = (uint32_t)shardCap;
+        Wf.lookAhead = lookAhead;
+        for (int i = 0; i < 4; ++i) Wf.segLen[i] = segLen[i];
+        for (int i = 0; i < 3; ++i) Wf.segRays[i] = segRays[i];
+        Wf.appendRays = appendRays;
+        Wf.regionRays = regionRays;
+        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
+        const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the extra segments of cut rays (a workgroup that finds it full leaves its rays whole)
+        const uint64_t ecap = qcap + extraCap;
+        if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
+        Wf.extraCap = (uint32_t)extraCap;
+        Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
+        if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
+            sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
+            sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
+            sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<unsigned long long>(cap, &Wf.laKey) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
+            sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
+            sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
+            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
+            sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
+            sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
+            sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
+            sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal) ||
+            sc->alloc<uint32_t>(RT_WF_ROUND_LOG, &Wf.roundLog))
+            return -1;
+        HIP_OK(hipMemsetAsync(Wf.roundLog, 0, sizeof(uint32_t) * RT_WF_ROUND_LOG, sc->stream));
+        HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, 2 * sizeof(uint32_t), sc->stream));
+        HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
+        HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void **)&G.hostStatus, sizeof(uint32_t) * RT_WF_STATUS_WORDS, hipHostMallocMapped));
+        memset(G.hostStatus, 0, sizeof(uint32_t) * RT_WF_STATUS_WORDS);
+        HIP_OK(hipHostGetDevicePointer((void **)&Wf.hostStatus, G.hostStatus, 0));
+        Wf.spinLimit = spinLimit;
+        // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
+        G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // setup / scatter: two generations of 8 resident workgroups per CU
+        G.traceBlocks = (uint32_t)(ecap / 256); // trace: one workgroup per 256 sorted entries, dispatched in order; surplus groups exit at once
+        G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
+        if (G.logicBlocks == 0) G.logicBlocks = 1;
     }
-    mark("camera lists");
-    {
-        const cl_uint *ids = nullptr;
-        if (sc->upload(sc->tileIds.data(), nt, &ids, "tileIds")) return -1;
-        D.tileIds = ids;
-    }
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');
+    if (const char *b = getenv("RT_WF_PLAN_ROUNDS")) sc->planCap = (uint32_t)strtoul(b, nullptr, 10);
+    if (const char *b = getenv("RT_WF_PLAN_GRID")) sc->planGridTiny = (strcmp(b, "tiny") == 0);
+    const char *env = getenv("RT_HIP_PIPELINE");
+    if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
+    return 0;
+}
 
-    // --- geometry: upload the ABI arrays, reshape on the device, drop the originals -------------------------------
-    {
-        for (uint32_t t = 0; t < d->triangleCount; ++t)
-            for (int k = 0; k < 3; ++k)
-                if ((uint32_t)d->triIndex[t].s[k] >= d->vertexCount) return fail("triangle %u references vertex %d of %u", t, d->triIndex[t].s[k], d->vertexCount);
-        void *dv = nullptr, *di = nullptr, *dm = nullptr, *du = nullptr, *dn = nullptr;
-        const uint64_t T = d->triangleCount ? d->triangleCount : 1, V = d->vertexCount ? d->vertexCount : 1;
-        DevScratch scratch; // the ABI arrays on the device, dropped once they are reshaped
-        HIP_OK(scratch.get(&dv, V * 16)); HIP_OK(scratch.get(&di, T * 16)); HIP_OK(scratch.get(&dm, T * 4));
-        HIP_OK(scratch.get(&du, T * 24)); HIP_OK(scratch.get(&dn, T * 48));
-        if (d->vertexCount) HIP_OK(hipMemcpyAsync(dv, d->vertex, (uint64_t)d->vertexCount * 16, hipMemcpyHostToDevice, sc->stream));
-        if (d->triangleCount) {
-            HIP_OK(hipMemcpyAsync(di, d->triIndex, (uint64_t)d->triangleCount * 16, hipMemcpyHostToDevice, sc->stream));
-            HIP_OK(hipMemcpyAsync(dm, d->triMaterial, (uint64_t)d->triangleCount * 4, hipMemcpyHostToDevice, sc->stream));
-            HIP_OK(hipMemcpyAsync(du, d->triUv, (uint64_t)d->triangleCount * 24, hipMemcpyHostToDevice, sc->stream));
-            HIP_OK(hipMemcpyAsync(dn, d->triNormal, (uint64_t)d->triangleCount * 48, hipMemcpyHostToDevice, sc->stream));
-        }
-        float *rec = nullptr, *shade = nullptr;
-        if (sc->alloc<float>(T * 16, &rec) || sc->alloc<float>(T * 24, &shade)) return -1;
-        HIP_OK(rtk_launch_prepare(d->triangleCount, dv, di, dm, du, dn, rec, shade, sc->stream));
-        HIP_OK(hipStreamSynchronize(sc->stream));
-        D.triRec = rec; D.triShade = shade;
-        for (uint32_t t = 0; t < d->triangleCount; ++t)
-            if (d->triMaterial[t] >= (cl_int)d->materialCount) return fail("triangle %u uses material %d of %u", t, d->triMaterial[t], d->materialCount);
+// the groups' views of the scene (same scene, a contiguous range of this instance's tile slots): refreshed whenever a part
+// was rebuilt
+void refresh_views(rtHipScene *sc)
+{
+    const RtDevScene &D = sc->dev;
+    for (auto &G : sc->groups) {
+        G.dev = D;
+        G.dev.tileIds = D.tileIds + G.slot0;
+        G.dev.tileCount = G.slot1 - G.slot0;
+        G.dev.camStart = D.camStart + (size_t)G.slot0 * RT_TILE_PIXELS;
+        G.dev.camEnd = D.camEnd + (size_t)G.slot0 * RT_TILE_PIXELS;
+        G.dev.tileBuf = D.tileBuf + (size_t)G.slot0 * 3 * RT_TILE_PIXELS;
     }
+}
 
+int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds, cl_uint tileCount)
+{
+    if (!d) return fail("null scene description");
+    if (d->width == 0 || d->height == 0) return fail("empty image %ux%u", d->width, d->height);
+    if (d->sampleCount == 0) return fail("sampleCount must be >= 1");
+    if (d->axesDiv != RT_GRID_DIV) return fail("axesDivCount %d unsupported (the reference builds %d, trianglelist.h:110)", d->axesDiv, RT_GRID_DIV);
+    if ((uint64_t)d->width * d->height > 0xffffffffull) return fail("image too large");
+    HIP_OK(hipSetDevice(sc->device));
+    HIP_OK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    if (sc->stager.init(sc->stream) != 0) return -1;
+    // RT_HIP_TIMING=1: where the time of a scene upload goes (stderr)
+    const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    auto tLast = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(sc->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "libraytrace_hip: scene build: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tLast).count());
+        tLast = now;
+    };
+    if (build_fixed(sc, d, tileIds, tileCount) != 0) return -1;
+    mark("tiles, outputs, bump tables");
+    if (build_geometry(sc, d) != 0) return -1;
     mark("geometry");
-    // --- grid ----------------------------------------------------------------------------------------------------
-    {
-        std::vector<float> planes(3 * (RT_GRID_DIV + 1));
-        for (int w = 0; w < 3; ++w)
-            for (int i = 0; i <= RT_GRID_DIV; ++i) planes[w * (RT_GRID_DIV + 1) + i] = d->boxMin[i].s[w];
-        if (sc->upload(planes.data(), planes.size(), &D.boxMin, "boxMin")) return -1;
-        const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
-        if (!d->gridStart) return fail("null scenePixelTriangleListStart");
-        const uint64_t listSize = d->gridStart[cells];
-        for (uint64_t c = 0; c < cells; ++c)
-            if (d->gridStart[c] > d->gridStart[c + 1]) return fail("scenePixelTriangleListStart is not monotone at cell %llu", (unsigned long long)c);
-        if (listSize && !d->gridList) return fail("null scenePixelTriangleList");
-        for (uint64_t i = 0; i < listSize; ++i)
-            if (d->gridList[i] >= d->triangleCount) return fail("grid list entry %llu = %u is not a triangle (count %u)", (unsigned long long)i, d->gridList[i], d->triangleCount);
-        if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
-        if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
-        mark("grid checks + upload");
-        std::vector<unsigned long long> bits((size_t)(RT_GRID_DIV / 4) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4), 0ull);
-        for (uint32_t z = 0; z < RT_GRID_DIV; ++z)
-            for (uint32_t y = 0; y < RT_GRID_DIV; ++y) {
-                const uint64_t row = (uint64_t)y * RT_GRID_DIV + (uint64_t)z * RT_GRID_DIV * RT_GRID_DIV;
-                unsigned long long *w = bits.data() + ((y >> 2) * (RT_GRID_DIV / 4)) + (size_t)(z >> 2) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4);
-                const uint32_t shift = ((y & 3) << 2) | ((z & 3) << 4);
-                for (uint32_t x = 0; x < RT_GRID_DIV; ++x)
-                    if (d->gridStart[row + x] != d->gridStart[row + x + 1]) w[x >> 2] |= 1ull << (shift | (x & 3));
-            }
-        if (sc->upload(bits.data(), bits.size(), &D.gridBits, "gridBits")) return -1;
-        mark("occupancy words");
-        // dense view: rank per block, first pair per non-empty cell (in block order, bit order inside a block), pairs
-        {
-            const size_t blocks = bits.size();
-            std::vector<uint32_t> rank(blocks), cellFirst, pairTri;
-            cellFirst.reserve(listSize + 1);
-            pairTri.reserve(listSize);
-            uint32_t running = 0;
-            for (size_t b = 0; b < blocks; ++b) {
-                rank[b] = running;
-                unsigned long long w = bits[b];
-                const uint32_t bx = (uint32_t)(b % 64), by = (uint32_t)((b / 64) % 64), bz = (uint32_t)(b / 4096);
-                while (w) {
-                    const int bit = __builtin_ctzll(w);
-                    w &= w - 1;
-                    const uint32_t cx = bx * 4 + (bit & 3), cy = by * 4 + ((bit >> 2) & 3), cz = bz * 4 + (bit >> 4);
-                    const uint64_t cell = cx + (uint64_t)RT_GRID_DIV * cy + (uint64_t)RT_GRID_DIV * RT_GRID_DIV * cz;
-                    cellFirst.push_back((uint32_t)pairTri.size());
-                    for (uint32_t i = d->gridStart[cell]; i < d->gridStart[cell + 1]; ++i) pairTri.push_back(d->gridList[i]);
-                    ++running;
-                }
-            }
-            cellFirst.push_back((uint32_t)pairTri.size());
-            if (pairTri.size() != listSize) return fail("internal: pair count %zu != list size %llu", pairTri.size(), (unsigned long long)listSize);
-            std::vector<uint32_t> block(blocks * 3);
-            for (size_t b = 0; b < blocks; ++b) {
-                block[3 * b + 0] = (uint32_t)(bits[b] & 0xffffffffull);
-                block[3 * b + 1] = (uint32_t)(bits[b] >> 32);
-                block[3 * b + 2] = rank[b];
-            }
-            // pair order on the device: the first candidate of every non-empty cell at the cell's dense id, then everybody's
-            // further candidates (rt_device.h, pairRec)
-            const size_t nCells = cellFirst.size() - 1;
-            std::vector<uint32_t> pairOrder(pairTri.size()), pairCount(pairTri.size(), 0u), cellRest(nCells ? nCells : 1, 0u);
-            {
-                size_t restAt = nCells;
-                for (size_t k = 0; k < nCells; ++k) {
-                    const uint32_t first = cellFirst[k], n = cellFirst[k + 1] - first;
-                    pairOrder[k] = pairTri[first];
-                    pairCount[k] = n;
-                    cellRest[k] = (uint32_t)restAt;
-                    for (uint32_t i = 1; i < n; ++i) pairOrder[restAt++] = pairTri[first + i];
-                }
-                if (restAt != pairTri.size()) return fail("internal: pair order covers %zu of %zu pairs", restAt, pairTri.size());
-            }
-            {
-                std::vector<uint32_t> sparse((size_t)3 * ((63u << 16 | 63u << 8 | 63u) + 1u), 0u);
-                for (size_t b = 0; b < blocks; ++b) {
-                    const size_t at = (b % 64) | (((b / 64) % 64) << 8) | ((b / 4096) << 16);
-                    sparse[3 * at + 0] = block[3 * b + 0]; sparse[3 * at + 1] = block[3 * b + 1]; sparse[3 * at + 2] = block[3 * b + 2];
-                }
-                if (sc->upload(sparse.data(), sparse.size(), &D.gridBlockSparse, "gridBlockSparse")) return -1;
-                HIP_OK(hipStreamSynchronize(sc->stream)); // `sparse` is freed at the end of this scope
-            }
-            if (sc->upload(cellRest.data(), nCells, &D.cellRest, "cellRest")) return -1;
-            D.cellCount = (uint32_t)nCells;
-            uint32_t *dPairTri = nullptr, *dPairCount = nullptr;
-            DevScratch scratch;
-            HIP_OK(scratch.get((void **)&dPairTri, (size_t)listSize * 4));
-            HIP_OK(scratch.get((void **)&dPairCount, (size_t)listSize * 4));
-            if (listSize) {
-                HIP_OK(hipMemcpyAsync(dPairTri, pairOrder.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
-                HIP_OK(hipMemcpyAsync(dPairCount, pairCount.data(), (size_t)listSize * 4, hipMemcpyHostToDevice, sc->stream));
-            }
-            float *pairRec = nullptr;
-            if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
-            HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, dPairTri, dPairCount, D.triRec, pairRec, sc->stream));
-            HIP_OK(hipStreamSynchronize(sc->stream));
-            D.pairRec = pairRec;
-            HIP_OK(hipStreamSynchronize(sc->stream));
-        }
-        HIP_OK(hipStreamSynchronize(sc->stream));
-    }
-
-    mark("dense grid view");
-    // --- materials -------------------------------------------------------------------------------------------------
-    {
-        D.materialCount = d->materialCount;
-        D.texelCount = d->texturesSize ? d->texturesSize : 1;
-        if (sc->upload((const uint32_t *)d->matSize, (uint64_t)d->materialCount * 10, &D.matSize, "materialImageSize")) return -1;
-        if (sc->upload((const int32_t *)d->matStart, (uint64_t)d->materialCount * 5, &D.matStart, "materialImageStart")) return -1;
-        if (sc->upload((const uint8_t *)d->textures, (uint64_t)d->texturesSize * 4, &D.textures, "textures")) return -1;
-        for (uint32_t m = 0; m < d->materialCount * 5; ++m) {
-            const uint64_t w = d->matSize[m].s[0], h = d->matSize[m].s[1];
-            if (w && ((int64_t)d->matStart[m] < 0 || (uint64_t)d->matStart[m] + w * h > d->texturesSize))
-                return fail("material channel %u: %llux%llu texels at %d exceed the %u-texel atlas", m, (unsigned long long)w, (unsigned long long)h, d->matStart[m], d->texturesSize);
-        }
-        // bump: xPart/yPart = (float)sin(dh*PI_F/2.f), normalPart factors = (float)cos(...) (raytrace_opencl.c:251-253)
-        // with dh = hE/255.f - h0/255.f.  Only 256x256 byte pairs exist: tabulate with the HOST libm -- the library
-        // the reference's C path calls -- so the device result is that library's, bit for bit.
-        std::vector<float> tsin(65536), tcos(65536);
-        for (int e = 0; e < 256; ++e)
-            for (int h = 0; h < 256; ++h) {
-                const float fe = (float)e / 255.f, fh = (float)h / 255.f;
-                const float arg = (fe - fh) * 3.14159265f / 2.f;
-                tsin[(e << 8) | h] = (float)std::sin((double)arg);
-                tcos[(e << 8) | h] = (float)std::cos((double)arg);
-            }
-        if (sc->upload(tsin.data(), tsin.size(), &D.bumpSin, "bumpSin")) return -1;
-        if (sc->upload(tcos.data(), tcos.size(), &D.bumpCos, "bumpCos")) return -1;
-        HIP_OK(hipStreamSynchronize(sc->stream));
-    }
-
-    // --- lights -----------------------------------------------------------------------------------------------------
-    {
-        D.lightCount = d->lightCount;
-        std::vector<float> spread(d->lightCount ? d->lightCount : 1, 0.f);
-        for (uint32_t j = 0; j < d->lightCount; ++j) {
-            const float *ld = d->lightDir[j].s;
-            const float dd = ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2];
-            // raytrace_opencl.c:594 (double sin * double sqrt, then one rounding to float)
-            spread[j] = (float)(std::sin((double)((d->lightRadius[j] / 2.f) * 3.14159265f / 180.f)) * std::sqrt((double)dd));
-        }
-        if (sc->upload(d->lightType, d->lightCount, &D.lightType, "lightType")) return -1;
-        if (sc->upload((const float *)d->lightPos, (uint64_t)d->lightCount * 4, &D.lightPos, "lightPosition")) return -1;
-        if (sc->upload((const float *)d->lightDir, (uint64_t)d->lightCount * 4, &D.lightDir, "lightDirection")) return -1;
-        if (sc->upload((const float *)d->lightCol, (uint64_t)d->lightCount * 4, &D.lightCol, "lightColour")) return -1;
-        if (sc->upload(d->lightRadius, d->lightCount, &D.lightRadius, "lightRadius")) return -1;
-        if (sc->upload(d->lightHalfAtt, d->lightCount, &D.lightHalfAtt, "lightHalfAttenuationDistance")) return -1;
-        if (sc->upload(spread.data(), d->lightCount, &D.lightSpread, "lightSpread")) return -1;
-        HIP_OK(hipStreamSynchronize(sc->stream));
-    }
-
-    // --- outputs ---------------------------------------------------------------------------------------------------
-    {
-        uint16_t *buf = nullptr;
-        if (sc->alloc<uint16_t>((uint64_t)nt * 3 * RT_TILE_PIXELS, &buf)) return -1;
-        HIP_OK(hipMemsetAsync(buf, 0, (uint64_t)nt * 3 * RT_TILE_PIXELS * 2, sc->stream));
-        D.tileBuf = buf;
-        unsigned long long *st = nullptr;
-        if (sc->alloc<unsigned long long>(8, &st)) return -1;
-        HIP_OK(hipMemsetAsync(st, 0, 64, sc->stream));
-        D.stats = st;
-        HIP_OK(hipStreamSynchronize(sc->stream));
-    }
-
+    if (build_grid(sc, d) != 0) return -1;
+    mark("grid + dense view");
+    if (build_camera(sc, d) != 0) return -1;
+    mark("camera lists");
+    if (build_materials(sc, d) != 0) return -1;
+    if (build_lights(sc, d) != 0) return -1;
     mark("materials + lights");
-    // --- wavefront pipeline buffers: worst case every pixel of every sample in a batch becomes a path ------------
-    {
-        if (d->lightCount >= 65536u) return fail("lightCount %u too large", d->lightCount);
-        hipDeviceProp_t prop;
-        HIP_OK(hipGetDeviceProperties(&prop, sc->device));
-        const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-        // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
-        // result, staging + sorted entry
-        uint32_t extraFactor = 6; // region B of the entry arrays, in units of the path capacity: a region-cut ray has up to 9 extra entries
-        if (const char *b = getenv("RT_WF_EXTRA_FACTOR")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) extraFactor = (uint32_t)v; }
-        const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 8) + 16;
-        // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
-        // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
-        uint64_t budget = 24ull << 30;
-        {
-            size_t freeB = 0, totalB = 0;
-            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB / 3 < budget) budget = freeB / 3;
-        }
-        if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
-        uint64_t sb = budget / (perPath * (pix ? pix : 1));
-        if (sb < 1) sb = 1;
-        if (sb > d->sampleCount) sb = d->sampleCount;
-        if (sb > 65535) sb = 65535; // the primary kernel's gridDim.y
-        sc->samplesPerBatch = (uint32_t)sb;
-        uint32_t groupCount = 1; // RT_WF_GROUPS: concurrent tile groups per instance (measured: no gain once rays are cut into segments)
-        if (const char *b = getenv("RT_WF_GROUPS")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) groupCount = (uint32_t)v; }
-        if (groupCount > nt) groupCount = nt ? (uint32_t)nt : 1u;
-        uint32_t lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
-        if (const char *b = getenv("RT_WF_LOOKAHEAD")) lookAhead = (b[0] != '0') ? 1u : 0u;
-        const bool multiLight = d->lightCount > 1;
-        // segment lengths by round size (rt_wavefront.hip, wf_setup_kernel); 4096 is longer than any walk = no cutting
-        uint32_t segLen[4] = { 4096u, 256u, 64u, 16u }, segRays[3] = { 700000u, 300000u, 30000u };
-        auto parse_list = [](const char *b, uint32_t *out, int n) {
-            for (int i = 0; i < n && b && *b; ++i) {
-                char *endp = nullptr;
-                const unsigned long v = strtoul(b, &endp, 10);
-                if (endp == b) break;
-                out[i] = (uint32_t)(v ? v : 1);
-                b = (*endp == ',') ? endp + 1 : endp;
-            }
-        };
-        parse_list(getenv("RT_WF_SEG"), segLen, 4);
-        parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
-        // rounds with at least this many rays are cut at region boundaries and traced region by region (rt_wavefront.hip, wf_setup_kernel)
-        uint32_t regionRays = 0xffffffffu; // off by default: measured slower than length order once a cell visit is one fabric request
-        if (const char *b = getenv("RT_WF_REGION_RAYS")) regionRays = (uint32_t)strtoul(b, nullptr, 10);
-        uint32_t spinLimit = 16384u; // a ray makes at most 766 cell visits = 96 walk phases; RT_WF_SPIN_LIMIT lowers the guard to test its error path
-        if (const char *b = getenv("RT_WF_SPIN_LIMIT")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) spinLimit = (uint32_t)v; }
-        uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
-        if (const char *b = getenv("RT_WF_APPEND_RAYS")) appendRays = (uint32_t)strtoul(b, nullptr, 10);
-        HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
-        sc->groups.resize(groupCount);
-        for (uint32_t g = 0; g < groupCount; ++g) {
-            rtHipScene::Group &G = sc->groups[g];
-            const uint32_t slot0 = (uint32_t)((uint64_t)nt * g / groupCount), slot1 = (uint32_t)((uint64_t)nt * (g + 1) / groupCount);
-            G.dev = D; // a view: same scene, a contiguous range of this instance's tile slots
-            G.dev.tileIds = D.tileIds + slot0;
-            G.dev.tileCount = slot1 - slot0;
-            G.dev.camStart = D.camStart + (size_t)slot0 * RT_TILE_PIXELS;
-            G.dev.camEnd = D.camEnd + (size_t)slot0 * RT_TILE_PIXELS;
-            G.dev.tileBuf = D.tileBuf + (size_t)slot0 * 3 * RT_TILE_PIXELS;
-            if (g > 0) HIP_OK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
-            HIP_OK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
-            // queue slices: the primary kernel's workgroups are dealt to the shards round-robin, 256 paths each at most
-            const uint64_t gpix = (uint64_t)G.dev.tileCount * RT_TILE_PIXELS;
-            const uint64_t primaryBlocks = (uint64_t)G.dev.tileCount * 64 * sb;
-            const uint64_t shardCap = ((primaryBlocks + RT_WF_SHARDS - 1) / RT_WF_SHARDS) * 256;
-            const uint64_t cap = shardCap * RT_WF_SHARDS;
-            if (cap > 0x7ffffff0ull) return fail("tile set too large for one batch");
-            RtWavefront &Wf = G.wf;
-            Wf.capacity = (uint32_t)cap;
-            Wf.shardCap = (uint32_t)shardCap;
-            Wf.lookAhead = lookAhead;
-            for (int i = 0; i < 4; ++i) Wf.segLen[i] = segLen[i];
-            for (int i = 0; i < 3; ++i) Wf.segRays[i] = segRays[i];
-            Wf.appendRays = appendRays;
-            Wf.regionRays = regionRays;
-            const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
-            const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the extra segments of cut rays (a workgroup that finds it full leaves its rays whole)
-            const uint64_t ecap = qcap + extraCap;
-            if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
-            Wf.extraCap = (uint32_t)extraCap;
-            Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
-            if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
-                sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
-                sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
-                sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<unsigned long long>(cap, &Wf.laKey) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
-                sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
-                sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
-                sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
-                sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
-                sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
-                sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
-                sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal) ||
-                sc->alloc<uint32_t>(RT_WF_ROUND_LOG, &Wf.roundLog))
-                return -1;
-            HIP_OK(hipMemsetAsync(Wf.roundLog, 0, sizeof(uint32_t) * RT_WF_ROUND_LOG, sc->stream));
-            HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, 2 * sizeof(uint32_t), sc->stream));
-            HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
-            HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
-            HIP_OK(hipHostMalloc((void **)&G.hostStatus, sizeof(uint32_t) * RT_WF_STATUS_WORDS, hipHostMallocMapped));
-            memset(G.hostStatus, 0, sizeof(uint32_t) * RT_WF_STATUS_WORDS);
-            HIP_OK(hipHostGetDevicePointer((void **)&Wf.hostStatus, G.hostStatus, 0));
-            Wf.spinLimit = spinLimit;
-            // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
-            G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // setup / scatter: two generations of 8 resident workgroups per CU
-            G.traceBlocks = (uint32_t)(ecap / 256); // trace: one workgroup per 256 sorted entries, dispatched in order; surplus groups exit at once
-            G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
-            if (G.logicBlocks == 0) G.logicBlocks = 1;
-        }
-        HIP_OK(hipStreamSynchronize(sc->stream));
-        mark("path state buffers");
-        if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');
-        if (const char *b = getenv("RT_WF_PLAN_ROUNDS")) sc->planCap = (uint32_t)strtoul(b, nullptr, 10);
-        if (const char *b = getenv("RT_WF_PLAN_GRID")) sc->planGridTiny = (strcmp(b, "tiny") == 0);
-        const char *env = getenv("RT_HIP_PIPELINE");
-        if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
-    }
+    // what only a kernel can tell about the inputs (ids inside the lists): one look at the error word
+    HIP_OK(rtp_validate(sc->dev.triangleCount, 0, 0, nullptr, nullptr, sc->camListSize, sc->dev.camList, nullptr, 0, nullptr, sc->prepErr, sc->stream));
+    HIP_OK(hipStreamSynchronize(sc->stream));
+    if (sc->check_prep() != 0) return -1;
+    if (build_wavefront(sc, d->sampleCount) != 0) return -1;
+    refresh_views(sc);
+    mark("path state buffers");
     return 0;
 }
 
@@ -763,7 +859,8 @@ void rtHipSceneDestroy(rtHipScene *sc)
         if (G.done) (void)hipEventDestroy(G.done);
     }
     if (sc->forkEvent) (void)hipEventDestroy(sc->forkEvent);
-    for (void *p : sc->allocs) (void)hipFree(p);
+    for (int part = 0; part < PART_COUNT; ++part) sc->release_part(part);
+    sc->stager.destroy();
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
 }

@@ -80,6 +80,14 @@ struct RtDevScene {
     unsigned long long *stats; // 7 counters, only touched by the counted kernel variant
 };
 
+// error bits of the device-side input validation (rt_scene_prep.hip)
+#define RT_PREP_ERR_TRI_INDEX 1u     // a triangle references a vertex that does not exist
+#define RT_PREP_ERR_TRI_MATERIAL 2u  // a triangle's material id is >= materialCount
+#define RT_PREP_ERR_CAM_ENTRY 4u     // a camera list entry is not a triangle
+#define RT_PREP_ERR_CAM_RANGE 8u     // a pixel's candidate range reaches past the camera list
+#define RT_PREP_ERR_GRID_MONOTONE 16u // scenePixelTriangleListStart is not monotone
+#define RT_PREP_ERR_GRID_ENTRY 32u   // a grid list entry is not a triangle
+
 // ---- wavefront pipeline buffers (rt_wavefront.hip) -------------------------------------------------------------------
 // A "path" is one sample of one pixel whose primary ray hit something; it gets a dense id `a` (allocated by the
 // primary stage) and lives in HBM between stages as structure-of-arrays state.  Rays that need the grid are appended
