@@ -171,6 +171,11 @@ typedef struct rtHipStats {
     uint64_t primarySamples, primaryCandidates, gridRays, gridCells, gridCandidates, shadedHits, texelFetches;
 } rtHipStats;
 
+/* RaytraceAll keeps the scenes of its last call resident and rebuilds only what changed (content hashes of the input arrays:
+ * geometry, grid, materials | lights | camera lists | sample count).  rtHipCacheClear frees them; RT_HIP_CACHE=0 makes every
+ * call build and free, like the reference (raytrace.c:330-489,594-602). */
+void rtHipCacheClear(void);
+
 /* Number of HIP devices (0 when none / no driver).  Never fails. */
 int rtHipDeviceCount(void);
 

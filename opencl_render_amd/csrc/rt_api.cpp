@@ -193,6 +193,8 @@ struct rtHipScene {
     uint32_t planCap = 0;      // RT_WF_PLAN_ROUNDS=n (test hook): planned frames issue at most n rounds, so that the too-short-plan path runs
     bool unverified = false;   // planned frames were issued since the last frame_finish()
     hipStream_t lastStream = nullptr; // where the last frame was issued
+    std::atomic<float> *progress = nullptr; // drop-in layer: where finished sample batches are reported (GetProgress, raytrace.c:566-587)
+    float progressBase = 0.f, progressSpan = 0.f;
     // per-stage device time of the frames since the last query: [primary, logic, trace, accum, sort]
     struct StageEvent { int stage; hipEvent_t a, b; };
     std::vector<StageEvent> stageEvents;
@@ -765,6 +767,10 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
             if (sampleCount > 1) // a one-sample frame's pixels were written by the kernels that finished them
                 HIP_OK(stage(3, on, [&] { return rtw_launch_accum(&G.dev, &G.wf, base == 0 ? 1 : 0, on); }));
         }
+        // a watched frame knows here that this batch's rounds are over: tell whoever polls GetProgress (raytrace.c:566-587)
+        if (!planned && sc->progress)
+            sc->progress->store(sc->progressBase + sc->progressSpan * (float)std::min<uint64_t>(sampleCount, (uint64_t)base + sc->samplesPerBatch) / (float)sampleCount,
+                                std::memory_order_relaxed);
     }
     if (!planned) { // adopt what this frame needed (the maximum over its batches and groups)
         uint32_t need = 1;
@@ -1084,6 +1090,111 @@ clock_t GetStartTime(void) { return (clock_t)g_startTime.load(std::memory_order_
 clock_t GetEndTime(void) { return (clock_t)g_endTime.load(std::memory_order_relaxed); }
 void ResetTime(void) { g_startTime.store(0, std::memory_order_relaxed); g_endTime.store(0, std::memory_order_relaxed); }
 
+} // extern "C"
+
+// ---- the drop-in layer's scene cache ("next" row 2) ---------------------------------------------------------
+// The reference rebuilds everything on every call: program, 35 buffers, tiles x samples launches (raytrace.c:330-489).  A second
+// Render click usually changes the camera, sometimes the sample count, rarely the scene.  The scenes of the last call stay in
+// HBM; the next call hashes its input arrays (all host threads, a few ms for a 1 M-triangle scene) and rebuilds only the parts
+// whose hash changed: geometry + grid + materials are the expensive ones (upload, triangle records, dense grid view), the
+// camera lists, the lights and the path-state buffers are cheap.  RT_HIP_CACHE=0 switches the cache off (every call builds and
+// frees, like the reference); rtHipCacheClear() frees what is held.
+namespace {
+
+inline uint64_t mix64(uint64_t v)
+{
+    v ^= v >> 32; v *= 0xd6e8feb86659fd93ull; v ^= v >> 32; v *= 0xd6e8feb86659fd93ull; v ^= v >> 32;
+    return v;
+}
+
+// content hash of one chunk: four independent multiply-rotate lanes over 32-byte blocks, then the tail
+uint64_t hash_chunk(const unsigned char *p, size_t n)
+{
+    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0xc2b2ae3d27d4eb4full, c = 0x165667b19e3779f9ull, d = 0x27d4eb2f165667c5ull;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        a = (a ^ w[0]) * 0x9fb21c651e98df25ull; a = (a << 29) | (a >> 35);
+        b = (b ^ w[1]) * 0x9fb21c651e98df25ull; b = (b << 29) | (b >> 35);
+        c = (c ^ w[2]) * 0x9fb21c651e98df25ull; c = (c << 29) | (c >> 35);
+        d = (d ^ w[3]) * 0x9fb21c651e98df25ull; d = (d << 29) | (d >> 35);
+    }
+    uint64_t tail = 0;
+    for (int k = 0; i < n; ++i, ++k) tail |= (uint64_t)p[i] << (8 * (k & 7)), a = (k & 7) == 7 ? mix64(a ^ tail) : a;
+    return mix64(a ^ mix64(b ^ mix64(c ^ mix64(d ^ tail ^ (uint64_t)n))));
+}
+
+struct HashJob { const void *ptr; size_t bytes; int group; };
+
+// hashes of the five input groups (geometry, grid, materials, lights, camera), computed chunk-parallel
+void hash_inputs(const std::vector<HashJob> &jobs, uint64_t out[5])
+{
+    struct Chunk { const unsigned char *p; size_t n; uint64_t h; int group; };
+    std::vector<Chunk> chunks;
+    const size_t piece = (size_t)2 << 20;
+    for (const HashJob &j : jobs) {
+        const unsigned char *p = (const unsigned char *)j.ptr;
+        size_t left = p ? j.bytes : 0;
+        chunks.push_back(Chunk{ nullptr, j.bytes, 0, j.group }); // the length always counts, also for an empty array
+        while (left) { const size_t n = std::min(piece, left); chunks.push_back(Chunk{ p, n, 0, j.group }); p += n; left -= n; }
+    }
+    unsigned threads = std::thread::hardware_concurrency();
+    threads = std::max(1u, std::min(threads ? threads : 1u, 16u));
+    std::atomic<size_t> next{ 0 };
+    auto work = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < chunks.size();)
+            chunks[i].h = chunks[i].p ? hash_chunk(chunks[i].p, chunks[i].n) : mix64(chunks[i].n + 0x51ull);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (int g = 0; g < 5; ++g) out[g] = 0x12345678u + g;
+    for (const Chunk &c : chunks) out[c.group] = mix64(out[c.group] * 0x100000001b3ull ^ c.h);
+}
+
+struct SceneCache {
+    std::vector<rtHipScene *> scenes;
+    std::vector<std::vector<cl_uint>> tiles; // per scene: its tile ids (empty = all)
+    int first = 0, count = 0, devices = 0;
+    uint32_t width = 0, height = 0, sampleCount = 0;
+    uint64_t hash[5] = { 0 };
+    bool valid = false;
+    // gather root (device `first`): row-major planes and, for several scenes, the peers' tile buffers
+    uint16_t *planes = nullptr;
+    uint16_t *gather = nullptr;
+    uint32_t *gatherIds = nullptr;
+    size_t gatherTiles = 0;
+    void clear()
+    {
+        for (rtHipScene *s : scenes) rtHipSceneDestroy(s);
+        scenes.clear(); tiles.clear();
+        if (valid || planes || gather || gatherIds) {
+            if (devices > 0) (void)hipSetDevice(first % devices);
+            if (planes) (void)hipFree(planes);
+            if (gather) (void)hipFree(gather);
+            if (gatherIds) (void)hipFree(gatherIds);
+        }
+        planes = nullptr; gather = nullptr; gatherIds = nullptr; gatherTiles = 0;
+        valid = false;
+    }
+};
+SceneCache g_cache;
+std::mutex g_cacheMutex;
+
+} // namespace
+
+extern "C" {
+
+void rtHipCacheClear(void)
+{
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    const std::string keep = g_error;
+    g_cache.clear();
+    g_error = keep;
+}
+
 cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_float3 cameraEye, cl_float3 cameraEyeToTopLeftVector,
                     cl_float3 cameraLeftToRightPixelSizeVector, cl_float3 cameraTopToBottomPixelSizeVector, cl_float cameraPixelSizeInv,
                     cl_uint *cameraPixelTriangleListStart, cl_uint *cameraPixelTriangleListEnd, cl_uint *cameraPixelTriangleList,
@@ -1096,21 +1207,28 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
                     cl_ushort *outputRed, cl_ushort *outputGreen, cl_ushort *outputBlue)
 {
     g_error.clear();
+    auto refuse = [&](const char *why) -> cl_bool {
+        fprintf(stderr, "libraytrace_hip: %s\n", why);
+        return CL_FALSE;
+    };
     if (computationType == 0) {
         // The reference's id 0 is its own in-thread C loop (raytrace.c:604-655).  This library is the device path
         // only; falling back to a CPU here would hide a missing GPU.  Fail loudly.
         fail("RaytraceAll: computationType 0 (\"Local CPU single thread\") is the reference's own C path and is not "
              "provided by libraytrace_hip; pick a HIP device (computationType >= 1)");
-        fprintf(stderr, "libraytrace_hip: %s\n", g_error.c_str());
-        return CL_FALSE;
+        return refuse(g_error.c_str());
     }
     const int n = rtHipDeviceCount();
+    // "All GPUs": one scene per device with the tiles dealt round-robin, one host thread per device while the scenes are built
+    // and the first frame watches its ray queue.  RT_HIP_VIRTUAL_DEVICES=k (test hook): the all-GPUs id deals the tiles over k
+    // instances that share the real devices, so the path runs on a one-GPU box.
+    int virt = 0;
+    if (const char *b = getenv("RT_HIP_VIRTUAL_DEVICES")) virt = atoi(b);
     const bool all = (n > 1 && computationType == (cl_uint)n + 1);
-    const bool virtualAll = n > 0 && computationType == (cl_uint)n + 1 && getenv("RT_HIP_VIRTUAL_DEVICES") && atoi(getenv("RT_HIP_VIRTUAL_DEVICES")) > 1;
-    if (n <= 0 || (!all && !virtualAll && computationType > (cl_uint)n)) {
+    const bool allVirtual = n > 0 && virt > 1 && computationType == (cl_uint)n + 1;
+    if (n <= 0 || (!all && !allVirtual && computationType > (cl_uint)n)) {
         fail("RaytraceAll: computationType %u but %d HIP device(s) present", computationType, n);
-        fprintf(stderr, "libraytrace_hip: %s\n", g_error.c_str());
-        return CL_FALSE;
+        return refuse(g_error.c_str());
     }
     if (!outputRed || !outputGreen || !outputBlue) { fail("RaytraceAll: null output plane"); return CL_FALSE; }
 
@@ -1133,37 +1251,102 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     d.texturesSize = texturesSize; d.textures = textures;
     d.lightCount = lightCount; d.lightType = lightType; d.lightPos = lightPosition; d.lightDir = lightDirection;
     d.lightCol = lightColour; d.lightRadius = lightRadius; d.lightHalfAtt = lightHalfAttenuationDistance;
+    if (d.width == 0 || d.height == 0 || (uint64_t)d.width * d.height > 0xffffffffull) { fail("RaytraceAll: bad image size %ux%u", d.width, d.height); return refuse(g_error.c_str()); }
+    if (d.axesDiv != RT_GRID_DIV || !d.gridStart) { fail("RaytraceAll: axesDivCount %d / null grid (the reference builds %d, trianglelist.h:110)", d.axesDiv, RT_GRID_DIV); return refuse(g_error.c_str()); }
 
-    // the OpenCL branch zeroes the planes before accumulating (raytrace.c:476,481,486)
     const size_t P = (size_t)d.width * d.height;
-    memset(outputRed, 0, P * sizeof(cl_ushort));
-    memset(outputGreen, 0, P * sizeof(cl_ushort));
-    memset(outputBlue, 0, P * sizeof(cl_ushort));
-
-    // "All GPUs": one scene per device with the tiles dealt round-robin, one host thread per device (a frame blocks its
-    // thread while the host looks at the ray queue between rounds, so the devices must not share one).
-    // RT_HIP_VIRTUAL_DEVICES=k (test hook): the all-GPUs id deals the tiles over k instances that share the real devices.
-    int virt = 0;
-    if (const char *b = getenv("RT_HIP_VIRTUAL_DEVICES")) virt = atoi(b);
-    const bool allVirtual = virt > 1 && computationType == (cl_uint)n + 1;
     const bool every = all || allVirtual;
     const int first = every ? 0 : (int)computationType - 1, count = allVirtual ? virt : (all ? n : 1);
-    const uint32_t tiles = ((d.width + RT_TILE - 1) / RT_TILE) * ((d.height + RT_TILE - 1) / RT_TILE);
-    std::vector<rtHipScene *> scenes((size_t)count, nullptr);
-    std::vector<std::string> errors((size_t)count);
-    std::vector<char> failed((size_t)count, 0);
+    const uint32_t tilesTotal = ((d.width + RT_TILE - 1) / RT_TILE) * ((d.height + RT_TILE - 1) / RT_TILE);
     g_progress.store(0.f, std::memory_order_relaxed);
     const long t0 = (long)clock();
     g_startTime.store(t0 ? t0 : 1, std::memory_order_relaxed); // must read non-zero once the kernel phase begins
     g_endTime.store(t0 ? t0 : 1, std::memory_order_relaxed);
-    auto work = [&](int g) { // create + render one device's share; errors are thread-local, so they are carried out by hand
-        std::vector<cl_uint> mine;
-        if (count > 1) {
-            for (uint32_t t = (uint32_t)g; t < tiles; t += (uint32_t)count) mine.push_back(t); // round-robin tile deal
-            if (mine.empty()) return;
+
+    // ---- what changed since the last call? ---------------------------------------------------------------------------------
+    const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
+    const uint64_t gridListSize = d.gridStart[cells];
+    uint64_t h[5];
+    const auto tCall = std::chrono::steady_clock::now();
+    {
+        const uint32_t scalars[8] = { d.vertexCount, d.triangleCount, d.materialCount, d.texturesSize, d.lightCount, d.width, d.height, 0u };
+        std::vector<HashJob> jobs = {
+            { d.vertex, (size_t)d.vertexCount * 16, 0 }, { d.triIndex, (size_t)d.triangleCount * 16, 0 }, { d.triMaterial, (size_t)d.triangleCount * 4, 0 },
+            { d.triUv, (size_t)d.triangleCount * 24, 0 }, { d.triNormal, (size_t)d.triangleCount * 48, 0 }, { scalars, sizeof scalars, 0 },
+            { d.boxMin, (size_t)(RT_GRID_DIV + 1) * 16, 1 }, { d.gridStart, (size_t)(cells + 1) * 4, 1 }, { d.gridList, (size_t)gridListSize * 4, 1 },
+            { d.matSize, (size_t)d.materialCount * 40, 2 }, { d.matStart, (size_t)d.materialCount * 20, 2 }, { d.textures, (size_t)d.texturesSize * 4, 2 },
+            { d.lightType, (size_t)d.lightCount * 4, 3 }, { d.lightPos, (size_t)d.lightCount * 16, 3 }, { d.lightDir, (size_t)d.lightCount * 16, 3 },
+            { d.lightCol, (size_t)d.lightCount * 16, 3 }, { d.lightRadius, (size_t)d.lightCount * 4, 3 }, { d.lightHalfAtt, (size_t)d.lightCount * 4, 3 },
+            { d.camStart, P * 4, 4 }, { d.camEnd, P * 4, 4 }, { d.camList, (size_t)d.camListSize * 4, 4 }, { d.eye, 4 * 17, 4 },
+        };
+        hash_inputs(jobs, h);
+    }
+    const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    const auto tHash = std::chrono::steady_clock::now();
+
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    SceneCache &C = g_cache;
+    bool useCache = true;
+    if (const char *b = getenv("RT_HIP_CACHE")) useCache = (b[0] != '0');
+    const bool sameSet = C.valid && C.first == first && C.count == count && C.devices == n && C.width == d.width && C.height == d.height &&
+                         (int)C.scenes.size() == count;
+    const bool reuse = useCache && sameSet && C.hash[0] == h[0] && C.hash[1] == h[1] && C.hash[2] == h[2];
+    const bool lightsChanged = !reuse || C.hash[3] != h[3];
+    const bool cameraChanged = !reuse || C.hash[4] != h[4];
+    const bool samplesChanged = !reuse || C.sampleCount != d.sampleCount;
+    if (!reuse) {
+        C.clear();
+        C.first = first; C.count = count; C.devices = n; C.width = d.width; C.height = d.height;
+        C.scenes.assign((size_t)count, nullptr);
+        C.tiles.assign((size_t)count, std::vector<cl_uint>());
+        if (count > 1)
+            for (int g = 0; g < count; ++g)
+                for (uint32_t t = (uint32_t)g; t < tilesTotal; t += (uint32_t)count) C.tiles[g].push_back(t); // round-robin tile deal
+    }
+    std::vector<std::string> errors((size_t)count);
+    std::vector<char> failed((size_t)count, 0);
+    auto work = [&](int g) { // build or update one device's scene, render its share; errors are thread-local, so they are carried out by hand
+        if (count > 1 && C.tiles[g].empty()) return; // more instances than tiles
+        bool ok = true;
+        if (!C.scenes[g]) {
+            C.scenes[g] = rtHipSceneCreate((first + g) % n, &d, C.tiles[g].empty() ? nullptr : C.tiles[g].data(), (cl_uint)C.tiles[g].size());
+            ok = C.scenes[g] != nullptr;
+        } else {
+            rtHipScene *sc = C.scenes[g];
+            ok = hipSetDevice(sc->device) == hipSuccess;
+            if (ok && lightsChanged) ok = build_lights(sc, &d) == 0;
+            if (ok && cameraChanged) {
+                ok = build_camera(sc, &d) == 0;
+                if (ok) { // ids inside the new list: one look at the validation word
+                    ok = rtp_validate(sc->dev.triangleCount, 0, 0, nullptr, nullptr, sc->camListSize, sc->dev.camList, nullptr, 0, nullptr, sc->prepErr, sc->stream) == hipSuccess &&
+                         hipStreamSynchronize(sc->stream) == hipSuccess && sc->check_prep() == 0;
+                }
+            }
+            if (ok && (samplesChanged || (sc->dev.lightCount > 1) != sc->wfMultiLight)) ok = build_wavefront(sc, d.sampleCount) == 0;
+            if (ok && (lightsChanged || cameraChanged)) sc->planRounds = 0; // other rays: the next frame watches its queue again
+            if (ok) refresh_views(sc);
         }
-        scenes[g] = rtHipSceneCreate((first + g) % n, &d, mine.empty() ? nullptr : mine.data(), (cl_uint)mine.size());
-        if (!scenes[g] || rtHipRenderTiles(scenes[g], nullptr) != 0 || rtHipSync(scenes[g], nullptr) != 0) { failed[g] = 1; errors[g] = g_error; }
+        if (ok) {
+            rtHipScene *sc = C.scenes[g];
+            sc->progress = &g_progress;
+            sc->progressBase = 0.999f * (float)g / (float)count;
+            sc->progressSpan = 0.999f / (float)count;
+            ok = rtHipRenderTiles(sc, nullptr) == 0;
+            if (ok && sc->unverified) { // a planned frame runs without the host: follow the batch counter its kernels bump
+                const uint32_t batches = (d.sampleCount + sc->samplesPerBatch - 1) / sc->samplesPerBatch * (uint32_t)sc->groups.size();
+                uint32_t before = 0;
+                for (auto &G : sc->groups) before += G.hostStatus[RT_WF_STATUS_BATCHES];
+                while (hipStreamQuery(sc->stream) == hipErrorNotReady) {
+                    uint32_t now = 0;
+                    for (auto &G : sc->groups) now += G.hostStatus[RT_WF_STATUS_BATCHES];
+                    g_progress.store(sc->progressBase + sc->progressSpan * (float)std::min(now - before, batches) / (float)batches, std::memory_order_relaxed);
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+            }
+            ok = ok && rtHipSync(sc, nullptr) == 0;
+            sc->progress = nullptr;
+        }
+        if (!ok) { failed[g] = 1; errors[g] = g_error; }
     };
     if (count == 1) work(0);
     else {
@@ -1174,18 +1357,75 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     bool ok = true;
     for (int g = 0; g < count; ++g)
         if (failed[g]) { ok = false; g_error = errors[g]; }
-    int done = 0;
-    for (int g = 0; g < count && ok; ++g) { // the planes are accumulated into by one thread
-        if (!scenes[g]) continue;
-        ok = rtHipReadback(scenes[g], outputRed, outputGreen, outputBlue) == 0;
-        g_progress.store(0.999f * (float)++done / (float)count, std::memory_order_relaxed); // capped like raytrace.c:580
+    const auto tRender = std::chrono::steady_clock::now();
+
+    // ---- gather on the root device: peers' tile buffers over the fabric, one de-tiling launch, one copy per plane to the caller -----
+    if (ok) {
+        auto gather = [&]() -> int {
+            rtHipScene *root = nullptr;
+            for (rtHipScene *s : C.scenes) if (s) { root = s; break; }
+            if (!root) return fail("RaytraceAll: nothing to render");
+            HIP_OK(hipSetDevice(root->device));
+            if (!C.planes) HIP_OK(hipMalloc((void **)&C.planes, 3 * P * sizeof(uint16_t)));
+            HIP_OK(hipMemsetAsync(C.planes, 0, 3 * P * sizeof(uint16_t), root->stream)); // the ABI's planes are zeroed first (raytrace.c:476,481,486)
+            const void *tileBuf = root->dev.tileBuf;
+            const cl_uint *ids = root->dev.tileIds;
+            size_t tiles = root->tileIds.size();
+            if (count > 1) {
+                // [scene][slot] tile buffers next to each other on the root, ids alongside; a peer's buffer travels device to device
+                size_t total = 0;
+                for (rtHipScene *s : C.scenes) if (s) total += s->tileIds.size();
+                if (C.gatherTiles != total) {
+                    if (C.gather) HIP_OK(hipFree(C.gather));
+                    if (C.gatherIds) HIP_OK(hipFree(C.gatherIds));
+                    C.gather = nullptr; C.gatherIds = nullptr;
+                    HIP_OK(hipMalloc((void **)&C.gather, total * 3 * RT_TILE_PIXELS * sizeof(uint16_t)));
+                    HIP_OK(hipMalloc((void **)&C.gatherIds, total * sizeof(uint32_t)));
+                    std::vector<uint32_t> allIds;
+                    for (rtHipScene *s : C.scenes) if (s) allIds.insert(allIds.end(), s->tileIds.begin(), s->tileIds.end());
+                    HIP_OK(hipMemcpy(C.gatherIds, allIds.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    C.gatherTiles = total;
+                }
+                size_t at = 0;
+                for (rtHipScene *s : C.scenes) {
+                    if (!s) continue;
+                    const size_t bytes = s->tileIds.size() * 3 * RT_TILE_PIXELS * sizeof(uint16_t);
+                    HIP_OK(hipMemcpyPeerAsync((char *)C.gather + at, root->device, s->dev.tileBuf, s->device, bytes, root->stream)); // (the scenes were synchronised above)
+                    at += bytes;
+                }
+                tileBuf = C.gather; ids = C.gatherIds; tiles = total;
+            }
+            HIP_OK(rtk_launch_detile(tileBuf, ids, (uint32_t)tiles, d.width, d.height, root->tilesX, C.planes, C.planes + P, C.planes + 2 * P, root->stream));
+            HIP_OK(hipStreamSynchronize(root->stream));
+            HIP_OK(hipMemcpy(outputRed, C.planes, P * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(outputGreen, C.planes + P, P * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(outputBlue, C.planes + 2 * P, P * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            return 0;
+        };
+        ok = gather() == 0;
     }
-    std::string keep = g_error;
-    for (rtHipScene *s : scenes) rtHipSceneDestroy(s);
-    g_error = keep;
+    if (ok) {
+        for (int i = 0; i < 5; ++i) C.hash[i] = h[i];
+        C.sampleCount = d.sampleCount;
+        C.valid = true;
+        g_progress.store(0.999f, std::memory_order_relaxed); // capped like raytrace.c:580; the caller sets 1.0 (render.cpp:1397)
+    }
+    if (timing) {
+        const auto tEnd = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "libraytrace_hip: RaytraceAll: %s; hashing %.1f ms, build/update + render %.1f ms, gather + copy out %.1f ms\n",
+                reuse ? (cameraChanged || lightsChanged || samplesChanged ? "scene reused, parts rebuilt" : "scene reused as it is") : "scene built",
+                ms(tCall, tHash), ms(tHash, tRender), ms(tRender, tEnd));
+    }
+    if (!ok || !useCache) {
+        const std::string keep = g_error;
+        C.clear();
+        g_error = keep;
+    }
     g_endTime.store((long)clock(), std::memory_order_relaxed);
     if (!ok) fprintf(stderr, "libraytrace_hip: RaytraceAll failed: %s\n", g_error.c_str());
     return ok ? CL_TRUE : CL_FALSE;
 }
 
 } // extern "C"
+

@@ -62,7 +62,7 @@ DROPIN_SYMBOLS = [
     "dot", "cross", "normalize", "vector", "bindf", "GetPointToLineSqLen", "RayIntersectsTriangle", "GetBoxAddress",
 ]
 RESIDENT_SYMBOLS = [
-    "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
+    "rtHipCacheClear", "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
     L.GetBoxAddress.restype = type("Int3", (C.Structure,), {"_fields_": [("s", C.c_int32 * 4)]})
     L.GetBoxAddress.argtypes = [i32, vp, Float3]
 
+    L.rtHipCacheClear.restype = None
     L.rtHipDeviceCount.restype = C.c_int
     L.rtHipLastError.restype = C.c_char_p
     L.rtHipSceneCreate.restype = vp

@@ -401,3 +401,63 @@ def test_primary_only_frames_issue_no_empty_rounds():
         assert_planes(rs.readback(), want, "primary_only, planned frame")
     finally:
         rs.close()
+
+
+def test_dropin_cache_rebuilds_exactly_what_changed():
+    """RaytraceAll keeps its last scene resident and rebuilds parts by content hash.  Every variation below must
+    give the oracle's planes for the CHANGED inputs: a stale part would show up as the previous picture."""
+    import copy
+    threads = os.cpu_count() or 1
+    base = S.make_soup(256, 192, 8000, 0.05, seed=51, samples=2)
+    R.build_lists(base)
+
+    def check(sc, what):
+        ok, r, g, b = R.raytrace_all(1, sc)
+        assert ok, R.last_error()
+        assert_planes((r, g, b), O.oracle_render(sc, threads=threads), what)
+        return r
+
+    first = check(base, "first call (scene built)")
+    assert np.array_equal(check(base, "second call, nothing changed (scene reused as it is)"), first)
+    moved = copy.copy(base)                       # one vertex moved: geometry hash changes, and so do both lists
+    moved.vertex = base.vertex.copy()
+    moved.vertex[0:3, :3] += np.float32(0.2)
+    R.build_lists(moved)
+    assert not np.array_equal(check(moved, "a vertex moved (scene rebuilt)"), first)
+    cam = copy.copy(moved)                        # camera moved: only the camera part is rebuilt
+    cam.eye = moved.eye.copy()
+    cam.eye[0] += np.float32(0.15)
+    R.build_camera_list(cam)
+    check(cam, "camera moved (camera lists rebuilt, geometry reused)")
+    more = copy.copy(cam)                         # sample count changed: path-state buffers rebuilt
+    more.sample_count = 5
+    check(more, "sample count changed")
+    lit = copy.copy(more)                         # a second light: lights rebuilt, path state re-sized for several lights
+    lights = S.pack_lights([dict(type=S.LIGHT_DISTANT, dir=(0.3, -0.8, 0.5)), dict(type=S.LIGHT_SPOT, pos=(0.5, 0.5, 1.0), col=(0.4, 0.5, 0.9), radius=0.1)])
+    lit.light_type, lit.light_pos, lit.light_dir, lit.light_col, lit.light_radius, lit.light_half_att = lights
+    check(lit, "lights changed")
+    dark = copy.copy(lit)                         # materials changed: rebuilt scene
+    dark.textures = lit.textures.copy()
+    dark.textures[:, :3] //= 2
+    check(dark, "texture atlas changed")
+    check(base, "back to the first scene")
+    R.lib().rtHipCacheClear()
+
+
+def test_dropin_second_call_on_an_unchanged_1m_scene_is_fast():
+    """the second RaytraceAll on an unchanged 1 M-triangle scene hashes its inputs, finds everything
+    resident and renders: a few milliseconds of wall time instead of a scene build (the reference rebuilds all of it,
+    raytrace.c:330-489)."""
+    import time
+    sc = _bench_scene("lambert_1m")
+    ok, r0, g0, b0 = R.raytrace_all(1, sc)
+    assert ok, R.last_error()
+    walls = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        ok, r, g, b = R.raytrace_all(1, sc)
+        walls.append(time.perf_counter() - t0)
+        assert ok and np.array_equal(r, r0) and np.array_equal(b, b0)
+    print(f"RaytraceAll on the resident 1 M-triangle scene: {[round(1e3 * w, 2) for w in walls]} ms wall (incl. the ctypes wrapper's three plane allocations)")
+    assert min(walls) < 0.030, walls
+    R.lib().rtHipCacheClear()
