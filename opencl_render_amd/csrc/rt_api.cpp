@@ -1269,7 +1269,7 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     uint64_t h[5];
     const auto tCall = std::chrono::steady_clock::now();
     {
-        const uint32_t scalars[8] = { d.vertexCount, d.triangleCount, d.materialCount, d.texturesSize, d.lightCount, d.width, d.height, 0u };
+        const uint32_t scalars[4] = { d.vertexCount, d.triangleCount, d.materialCount, d.texturesSize }; // (light count and image size have their own groups / keys)
         std::vector<HashJob> jobs = {
             { d.vertex, (size_t)d.vertexCount * 16, 0 }, { d.triIndex, (size_t)d.triangleCount * 16, 0 }, { d.triMaterial, (size_t)d.triangleCount * 4, 0 },
             { d.triUv, (size_t)d.triangleCount * 24, 0 }, { d.triNormal, (size_t)d.triangleCount * 48, 0 }, { scalars, sizeof scalars, 0 },

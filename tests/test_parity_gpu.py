@@ -419,9 +419,9 @@ def test_dropin_cache_rebuilds_exactly_what_changed():
 
     first = check(base, "first call (scene built)")
     assert np.array_equal(check(base, "second call, nothing changed (scene reused as it is)"), first)
-    moved = copy.copy(base)                       # one vertex moved: geometry hash changes, and so do both lists
+    moved = copy.copy(base)                       # vertices moved: geometry hash changes, and so do both lists
     moved.vertex = base.vertex.copy()
-    moved.vertex[0:3, :3] += np.float32(0.2)
+    moved.vertex[0:1500, 0] += np.float32(0.2)  # 500 triangles shifted sideways
     R.build_lists(moved)
     assert not np.array_equal(check(moved, "a vertex moved (scene rebuilt)"), first)
     cam = copy.copy(moved)                        # camera moved: only the camera part is rebuilt
