@@ -137,7 +137,12 @@ def main():
         log(f"scene resident on the device after {t_upload:.2f}s ({rs.device_bytes() / 1e9:.2f} GB)" if hasattr(rs, "device_bytes") else f"scene resident after {t_upload:.2f}s")
     buf_ptr, buf_bytes = rs.tile_buffer()
     tile_tensor = T.alias_device_bytes(buf_ptr, buf_bytes, device)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    # One real stream for the whole frame: the rays' kernels, the gather and the de-tiling launch must be ordered behind each
+    # other ON THE DEVICE (a frame is issued without any host synchronisation).  Stream 0 would mean "the scene's own stream" to
+    # the library and the default stream to torch -- two different queues.
+    work_stream = torch.cuda.Stream(device)
+    stream = work_stream.cuda_stream
+    assert stream != 0
 
     planes = ids_dev = None
     slots = T.max_tiles_per_rank(W, H, world)
@@ -152,16 +157,19 @@ def main():
         ids_dev = torch.from_numpy(ids.reshape(-1)).to(device)
     L = R.lib()
 
-    def frame():
-        rs.render(stream)
-        gathered = T.gather_tiles(tile_tensor, W, H, rank, world)
-        if rank == 0:
-            planes.zero_()  # the kernel accumulates (saturating), like the ABI's planes
-            base = planes.data_ptr()
-            rc = L.rtHipDetile(local_rank, gathered.data_ptr(), ids_dev.data_ptr(), world * slots, W, H,
-                               base, base + 2 * P, base + 4 * P, stream)
-            if rc != 0:
-                raise RuntimeError("rtHipDetile: " + R.last_error())
+    def frame(to_host=None):
+        with torch.cuda.stream(work_stream):
+            rs.render(stream)
+            gathered = T.gather_tiles(tile_tensor, W, H, rank, world)
+            if rank == 0:
+                planes.zero_()  # the kernel accumulates (saturating), like the ABI's planes
+                base = planes.data_ptr()
+                rc = L.rtHipDetile(local_rank, gathered.data_ptr(), ids_dev.data_ptr(), world * slots, W, H,
+                                   base, base + 2 * P, base + 4 * P, stream)
+                if rc != 0:
+                    raise RuntimeError("rtHipDetile: " + R.last_error())
+                if to_host is not None:
+                    to_host.copy_(planes, non_blocking=True)
 
     def barrier():
         if world > 1:
@@ -190,17 +198,15 @@ def main():
     ms_with_d2h = None
     if rank == 0:
         host_planes = torch.empty(3 * P * 2, dtype=torch.uint8, pin_memory=True)
+    else:
+        host_planes = None
     for _ in range(2):
-        frame()
-        if rank == 0:
-            host_planes.copy_(planes, non_blocking=True)
+        frame(host_planes)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        frame()
-        if rank == 0:
-            host_planes.copy_(planes, non_blocking=True)
+        frame(host_planes)
     torch.cuda.synchronize()
     barrier()
     ms_with_d2h = 1e3 * (time.perf_counter() - t1) / args.steps
