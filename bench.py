@@ -162,12 +162,12 @@ def main():
             rs.render(stream)
             gathered = T.gather_tiles(tile_tensor, W, H, rank, world)
             if rank == 0:
-                planes.zero_()  # the kernel accumulates (saturating), like the ABI's planes
+                # every pixel of the frame belongs to exactly one tile of the deal: the root writes its planes (no zero fill + add)
                 base = planes.data_ptr()
-                rc = L.rtHipDetile(local_rank, gathered.data_ptr(), ids_dev.data_ptr(), world * slots, W, H,
-                                   base, base + 2 * P, base + 4 * P, stream)
+                rc = L.rtHipDetileStore(local_rank, gathered.data_ptr(), ids_dev.data_ptr(), world * slots, W, H,
+                                        base, base + 2 * P, base + 4 * P, stream)
                 if rc != 0:
-                    raise RuntimeError("rtHipDetile: " + R.last_error())
+                    raise RuntimeError("rtHipDetileStore: " + R.last_error())
                 if to_host is not None:
                     to_host.copy_(planes, non_blocking=True)
 

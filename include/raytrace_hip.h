@@ -239,6 +239,11 @@ uint64_t rtHipTileBufferBytes(const rtHipScene *scene);
 int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIdsDevice, cl_uint tileCount,
                 cl_uint width, cl_uint height, void *planeR, void *planeG, void *planeB, void *stream);
 
+/* The same without the accumulate: the planes' pixels are overwritten by the tiles' (a gather root that would zero its planes first
+ * anyway -- every pixel belongs to exactly one tile of a deal).  Pixels no tile covers keep their value. */
+int rtHipDetileStore(int device, const void *tileBuffer, const cl_uint *tileIdsDevice, cl_uint tileCount,
+                     cl_uint width, cl_uint height, void *planeR, void *planeG, void *planeB, void *stream);
+
 /* Blocks until the scene's work is done, then adds its tiles into three HOST planes (width*height u16 each). */
 int rtHipReadback(rtHipScene *scene, cl_ushort *outR, cl_ushort *outG, cl_ushort *outB);
 

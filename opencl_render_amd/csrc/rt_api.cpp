@@ -28,7 +28,7 @@ extern "C" hipError_t rtk_launch_prepare(uint32_t triangleCount, const void *ver
                                          const void *triUv, const void *triNormal, float *triRec, float *triShade, hipStream_t stream);
 extern "C" hipError_t rtk_launch_gather_pairs(uint32_t pairCount, const uint32_t *pairTri, const uint32_t *pairInfo, const float *triRec, float *pairRec, hipStream_t stream);
 extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
-                                        uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream);
+                                        uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, int accumulate, hipStream_t stream);
 
 extern "C" hipError_t rtp_validate(uint32_t T, uint32_t V, uint32_t M, const void *triIndex, const int *triMaterial, uint64_t camListSize,
                                    const uint32_t *camList, const uint32_t *gridStart, uint64_t gridListSize, const uint32_t *gridList, uint32_t *err,
@@ -963,7 +963,18 @@ int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIdsDevice
     if (width == 0 || height == 0) return fail("empty image");
     HIP_OK(hipSetDevice(device));
     const uint32_t tilesX = (width + RT_TILE - 1) / RT_TILE;
-    HIP_OK(rtk_launch_detile(tileBuffer, tileIdsDevice, tileCount, width, height, tilesX, planeR, planeG, planeB, (hipStream_t)stream));
+    HIP_OK(rtk_launch_detile(tileBuffer, tileIdsDevice, tileCount, width, height, tilesX, planeR, planeG, planeB, 1, (hipStream_t)stream));
+    return 0;
+}
+
+int rtHipDetileStore(int device, const void *tileBuffer, const cl_uint *tileIdsDevice, cl_uint tileCount, cl_uint width, cl_uint height,
+                     void *planeR, void *planeG, void *planeB, void *stream)
+{
+    if (!tileBuffer || !tileIdsDevice || !planeR || !planeG || !planeB) return fail("null argument");
+    if (width == 0 || height == 0) return fail("empty image");
+    HIP_OK(hipSetDevice(device));
+    const uint32_t tilesX = (width + RT_TILE - 1) / RT_TILE;
+    HIP_OK(rtk_launch_detile(tileBuffer, tileIdsDevice, tileCount, width, height, tilesX, planeR, planeG, planeB, 0, (hipStream_t)stream));
     return 0;
 }
 
@@ -1367,7 +1378,8 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
             if (!root) return fail("RaytraceAll: nothing to render");
             HIP_OK(hipSetDevice(root->device));
             if (!C.planes) HIP_OK(hipMalloc((void **)&C.planes, 3 * P * sizeof(uint16_t)));
-            HIP_OK(hipMemsetAsync(C.planes, 0, 3 * P * sizeof(uint16_t), root->stream)); // the ABI's planes are zeroed first (raytrace.c:476,481,486)
+            // (the ABI's planes are zeroed first, raytrace.c:476,481,486, and every pixel belongs to exactly one tile of the deal:
+            // the de-tiling launch simply writes them)
             const void *tileBuf = root->dev.tileBuf;
             const cl_uint *ids = root->dev.tileIds;
             size_t tiles = root->tileIds.size();
@@ -1395,7 +1407,7 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
                 }
                 tileBuf = C.gather; ids = C.gatherIds; tiles = total;
             }
-            HIP_OK(rtk_launch_detile(tileBuf, ids, (uint32_t)tiles, d.width, d.height, root->tilesX, C.planes, C.planes + P, C.planes + 2 * P, root->stream));
+            HIP_OK(rtk_launch_detile(tileBuf, ids, (uint32_t)tiles, d.width, d.height, root->tilesX, C.planes, C.planes + P, C.planes + 2 * P, 0, root->stream));
             HIP_OK(hipStreamSynchronize(root->stream));
             HIP_OK(hipMemcpy(outputRed, C.planes, P * sizeof(uint16_t), hipMemcpyDeviceToHost));
             HIP_OK(hipMemcpy(outputGreen, C.planes + P, P * sizeof(uint16_t), hipMemcpyDeviceToHost));

@@ -317,8 +317,11 @@ __global__ __launch_bounds__(256) void rt_prepare_triangles(uint32_t triangleCou
     sh[22] = 0.f; sh[23] = 0.f;
 }
 
-// De-tiles [slot][3][128*128] tile buffers into three row-major planes with a saturating add (the ABI accumulates
-// into the caller's planes, raytrace_opencl.c:729-740).  One thread per 8 consecutive pixels of a tile row.
+// De-tiles [slot][3][128*128] tile buffers into three row-major planes.  ACCUMULATE: saturating add into what is there (the ABI
+// accumulates into the caller's planes, raytrace_opencl.c:729-740); otherwise the planes' pixels are simply written (a gather
+// root whose planes would be zeroed first anyway).  One thread per 8 consecutive pixels of a tile row: 16 bytes in, 16 bytes out
+// when the row segment is whole and the image width keeps it aligned, pixel by pixel otherwise.
+template <bool ACCUMULATE>
 __global__ __launch_bounds__(256) void rt_detile_kernel(const uint16_t *__restrict__ tileBuf, const uint32_t *__restrict__ tileIds,
                                                         uint32_t tileCount, uint32_t width, uint32_t height, uint32_t tilesX,
                                                         uint16_t *planeR, uint16_t *planeG, uint16_t *planeB)
@@ -338,8 +341,22 @@ __global__ __launch_bounds__(256) void rt_detile_kernel(const uint16_t *__restri
     const uint16_t *src = tileBuf + ((size_t)slot * 3 + plane) * RT_TILE_PIXELS + row * RT_TILE + seg * 8;
     uint16_t *dst = (plane == 0 ? planeR : plane == 1 ? planeG : planeB) + (size_t)gy * width + gx0;
     const uint32_t n = (width - gx0 < 8) ? width - gx0 : 8;
+    if (n == 8 && (width & 7u) == 0u && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+        uint4 v = *reinterpret_cast<const uint4 *>(src);
+        if (ACCUMULATE) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(dst);
+            auto add2 = [](uint32_t a, uint32_t b) { // two saturating u16 adds in one word
+                uint32_t lo = (a & 0xffffu) + (b & 0xffffu), hi = (a >> 16) + (b >> 16);
+                lo = lo > 0xffffu ? 0xffffu : lo; hi = hi > 0xffffu ? 0xffffu : hi;
+                return lo | (hi << 16);
+            };
+            v = make_uint4(add2(v.x, o.x), add2(v.y, o.y), add2(v.z, o.z), add2(v.w, o.w));
+        }
+        *reinterpret_cast<uint4 *>(dst) = v;
+        return;
+    }
     for (uint32_t i = 0; i < n; ++i) {
-        uint32_t v = (uint32_t)dst[i] + (uint32_t)src[i];
+        uint32_t v = (uint32_t)src[i] + (ACCUMULATE ? (uint32_t)dst[i] : 0u);
         dst[i] = (uint16_t)(v > 0xFFFFu ? 0xFFFFu : v);
     }
 }
@@ -389,11 +406,15 @@ extern "C" hipError_t rtk_launch_prepare(uint32_t triangleCount, const void *ver
 }
 
 extern "C" hipError_t rtk_launch_detile(const void *tileBuf, const uint32_t *tileIds, uint32_t tileCount, uint32_t width,
-                                        uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, hipStream_t stream)
+                                        uint32_t height, uint32_t tilesX, void *planeR, void *planeG, void *planeB, int accumulate, hipStream_t stream)
 {
     const uint32_t total = tileCount * 3 * RT_TILE * (RT_TILE / 8);
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_detile_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const uint16_t *)tileBuf, tileIds, tileCount,
-                       width, height, tilesX, (uint16_t *)planeR, (uint16_t *)planeG, (uint16_t *)planeB);
+    if (accumulate)
+        hipLaunchKernelGGL(rt_detile_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, stream, (const uint16_t *)tileBuf, tileIds, tileCount,
+                           width, height, tilesX, (uint16_t *)planeR, (uint16_t *)planeG, (uint16_t *)planeB);
+    else
+        hipLaunchKernelGGL(rt_detile_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, stream, (const uint16_t *)tileBuf, tileIds, tileCount,
+                           width, height, tilesX, (uint16_t *)planeR, (uint16_t *)planeG, (uint16_t *)planeB);
     return hipGetLastError();
 }

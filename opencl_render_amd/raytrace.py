@@ -64,7 +64,7 @@ DROPIN_SYMBOLS = [
 RESIDENT_SYMBOLS = [
     "rtHipCacheClear", "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
-    "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipReadback", "rtHipSync",
+    "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipDetileStore", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
     "rtHipDeviceKat",
     "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
     L.rtHipTileBufferBytes.restype = u64
     L.rtHipTileBufferBytes.argtypes = [vp]
     L.rtHipDetile.argtypes = [C.c_int, vp, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.rtHipDetileStore.argtypes = [C.c_int, vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.rtHipReadback.argtypes = [vp, vp, vp, vp]
     L.rtHipSync.argtypes = [vp, vp]
     L.rtHipKernelTime.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]

@@ -461,3 +461,35 @@ def test_dropin_second_call_on_an_unchanged_1m_scene_is_fast():
     print(f"RaytraceAll on the resident 1 M-triangle scene: {[round(1e3 * w, 2) for w in walls]} ms wall (incl. the ctypes wrapper's three plane allocations)")
     assert min(walls) < 0.030, walls
     R.lib().rtHipCacheClear()
+
+
+@pytest.mark.parametrize("name", ["odd_size_multi_tile", "lambert_distant"])  # 200x150 (rows of whole 16-byte segments) and 64x48
+def test_device_detile_store_and_accumulate(name):
+    """rtHipDetileStore writes the tiles' pixels into row-major device planes, rtHipDetile adds them with saturation
+    (raytrace_opencl.c:729-740); both in 16-byte pieces where the image width allows and pixel by pixel elsewhere."""
+    import torch
+    sc, want = load_golden_scene(name)
+    L = R.lib()
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        rs.sync()
+        ptr, nbytes = rs.tile_buffer()
+        P = sc.pixels
+        dev = torch.device("cuda", 0)
+        planes = torch.from_numpy(np.full(3 * P, 60000, np.uint16).view(np.int16)).to(dev)  # 2-byte elements; viewed as u16 below
+        ids = torch.arange(R.tile_count(sc.width, sc.height), dtype=torch.int32, device=dev)
+        base = planes.data_ptr()
+        torch.cuda.synchronize()
+        assert L.rtHipDetileStore(0, ptr, ids.data_ptr(), len(ids), sc.width, sc.height, base, base + 2 * P, base + 4 * P, None) == 0
+        torch.cuda.synchronize()
+        got = planes.cpu().numpy().view(np.uint16).reshape(3, sc.height, sc.width)
+        assert_planes(got, want, name + " (store)")
+        assert L.rtHipDetile(0, ptr, ids.data_ptr(), len(ids), sc.width, sc.height, base, base + 2 * P, base + 4 * P, None) == 0
+        assert L.rtHipDetile(0, ptr, ids.data_ptr(), len(ids), sc.width, sc.height, base, base + 2 * P, base + 4 * P, None) == 0
+        torch.cuda.synchronize()
+        got = planes.cpu().numpy().view(np.uint16).reshape(3, sc.height, sc.width)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, np.minimum(3 * w.astype(np.int64), 65535).astype(np.uint16))
+    finally:
+        rs.close()
