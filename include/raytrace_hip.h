@@ -244,6 +244,12 @@ int rtHipDetile(int device, const void *tileBuffer, const cl_uint *tileIdsDevice
 int rtHipDetileStore(int device, const void *tileBuffer, const cl_uint *tileIdsDevice, cl_uint tileCount,
                      cl_uint width, cl_uint height, void *planeR, void *planeG, void *planeB, void *stream);
 
+/* Plain device memory for hosts that do not include HIP headers (a gather root's planes): allocate, free, and a blocking copy
+ * (toDevice != 0: host -> device, else device -> host; the device is synchronised first). */
+void *rtHipDeviceAlloc(int device, uint64_t bytes);
+void  rtHipDeviceFree(int device, void *p);
+int   rtHipDeviceCopy(int device, void *dst, const void *src, uint64_t bytes, int toDevice);
+
 /* Blocks until the scene's work is done, then adds its tiles into three HOST planes (width*height u16 each). */
 int rtHipReadback(rtHipScene *scene, cl_ushort *outR, cl_ushort *outG, cl_ushort *outB);
 

@@ -978,6 +978,25 @@ int rtHipDetileStore(int device, const void *tileBuffer, const cl_uint *tileIdsD
     return 0;
 }
 
+// Plain device memory for hosts that do not include HIP headers (a gather root's planes, test buffers).
+void *rtHipDeviceAlloc(int device, uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail("rtHipDeviceAlloc(%d, %llu) failed", device, (unsigned long long)bytes); return nullptr; }
+    return p;
+}
+void rtHipDeviceFree(int device, void *p)
+{
+    if (p && hipSetDevice(device) == hipSuccess) (void)hipFree(p);
+}
+int rtHipDeviceCopy(int device, void *dst, const void *src, uint64_t bytes, int toDevice)
+{
+    HIP_OK(hipSetDevice(device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(dst, src, bytes, toDevice ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rtHipSync(rtHipScene *sc, void *stream)
 {
     if (!sc) return fail("null scene");

@@ -64,7 +64,7 @@ DROPIN_SYMBOLS = [
 RESIDENT_SYMBOLS = [
     "rtHipCacheClear", "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
-    "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipDetileStore", "rtHipReadback", "rtHipSync",
+    "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipDetileStore", "rtHipDeviceAlloc", "rtHipDeviceFree", "rtHipDeviceCopy", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
     "rtHipDeviceKat",
     "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
@@ -136,6 +136,11 @@ def lib() -> C.CDLL:
     L.rtHipDetile.argtypes = [C.c_int, vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.rtHipDetileStore.argtypes = [C.c_int, vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.rtHipReadback.argtypes = [vp, vp, vp, vp]
+    L.rtHipDeviceAlloc.restype = vp
+    L.rtHipDeviceAlloc.argtypes = [C.c_int, u64]
+    L.rtHipDeviceFree.restype = None
+    L.rtHipDeviceFree.argtypes = [C.c_int, vp]
+    L.rtHipDeviceCopy.argtypes = [C.c_int, vp, vp, u64, C.c_int]
     L.rtHipSync.argtypes = [vp, vp]
     L.rtHipKernelTime.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.rtHipBuildCameraList.argtypes = [u32, u32, vp, vp, vp, vp, f32, u32, vp, vp, C.c_int,

@@ -467,29 +467,35 @@ def test_dropin_second_call_on_an_unchanged_1m_scene_is_fast():
 def test_device_detile_store_and_accumulate(name):
     """rtHipDetileStore writes the tiles' pixels into row-major device planes, rtHipDetile adds them with saturation
     (raytrace_opencl.c:729-740); both in 16-byte pieces where the image width allows and pixel by pixel elsewhere."""
-    import torch
+    import ctypes as C
     sc, want = load_golden_scene(name)
     L = R.lib()
     rs = R.ResidentScene(sc, 0)
+    P = sc.pixels
+    planes = L.rtHipDeviceAlloc(0, 6 * P)
+    ids_host = np.arange(R.tile_count(sc.width, sc.height), dtype=np.uint32)
+    ids = L.rtHipDeviceAlloc(0, ids_host.nbytes)
+    assert planes and ids
+
+    def read():
+        host = np.zeros(3 * P, np.uint16)
+        assert L.rtHipDeviceCopy(0, host.ctypes.data_as(C.c_void_p), planes, 6 * P, 0) == 0
+        return host.reshape(3, sc.height, sc.width)
+
     try:
         rs.render()
         rs.sync()
-        ptr, nbytes = rs.tile_buffer()
-        P = sc.pixels
-        dev = torch.device("cuda", 0)
-        planes = torch.from_numpy(np.full(3 * P, 60000, np.uint16).view(np.int16)).to(dev)  # 2-byte elements; viewed as u16 below
-        ids = torch.arange(R.tile_count(sc.width, sc.height), dtype=torch.int32, device=dev)
-        base = planes.data_ptr()
-        torch.cuda.synchronize()
-        assert L.rtHipDetileStore(0, ptr, ids.data_ptr(), len(ids), sc.width, sc.height, base, base + 2 * P, base + 4 * P, None) == 0
-        torch.cuda.synchronize()
-        got = planes.cpu().numpy().view(np.uint16).reshape(3, sc.height, sc.width)
-        assert_planes(got, want, name + " (store)")
-        assert L.rtHipDetile(0, ptr, ids.data_ptr(), len(ids), sc.width, sc.height, base, base + 2 * P, base + 4 * P, None) == 0
-        assert L.rtHipDetile(0, ptr, ids.data_ptr(), len(ids), sc.width, sc.height, base, base + 2 * P, base + 4 * P, None) == 0
-        torch.cuda.synchronize()
-        got = planes.cpu().numpy().view(np.uint16).reshape(3, sc.height, sc.width)
-        for g, w in zip(got, want):
+        ptr, _ = rs.tile_buffer()
+        fill = np.full(3 * P, 60000, np.uint16)
+        assert L.rtHipDeviceCopy(0, planes, fill.ctypes.data_as(C.c_void_p), 6 * P, 1) == 0
+        assert L.rtHipDeviceCopy(0, ids, ids_host.ctypes.data_as(C.c_void_p), ids_host.nbytes, 1) == 0
+        args = (0, ptr, ids, len(ids_host), sc.width, sc.height, planes, planes + 2 * P, planes + 4 * P, None)
+        assert L.rtHipDetileStore(*args) == 0
+        assert_planes(read(), want, name + " (store)")
+        assert L.rtHipDetile(*args) == 0 and L.rtHipDetile(*args) == 0
+        for g, w in zip(read(), want):
             assert np.array_equal(g, np.minimum(3 * w.astype(np.int64), 65535).astype(np.uint16))
     finally:
         rs.close()
+        L.rtHipDeviceFree(0, planes)
+        L.rtHipDeviceFree(0, ids)
