@@ -430,6 +430,20 @@ int build_materials(rtHipScene *sc, const rtHipSceneDesc *d)
         if (w && ((int64_t)d->matStart[m] < 0 || (uint64_t)d->matStart[m] + w * h > d->texturesSize))
             return fail("material channel %u: %llux%llu texels at %d exceed the %u-texel atlas", m, (unsigned long long)w, (unsigned long long)h, d->matStart[m], d->texturesSize);
     }
+    { // the per-material channel descriptors of rt_device.h
+        std::vector<uint32_t> rec((size_t)d->materialCount * 8, 0u);
+        for (uint32_t m = 0; m < d->materialCount; ++m)
+            for (int c = 0; c < 5; ++c) {
+                const uint32_t w = d->matSize[5 * m + c].s[0], h = d->matSize[5 * m + c].s[1];
+                uint32_t desc = 0u;
+                if (w == 1u && h == 1u) {
+                    const cl_uchar *px = d->textures[d->matStart[5 * m + c]].s; // (start was checked above)
+                    desc = 0x80000000u | (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+                } else if (w) desc = 0x40000000u; // (w > 0, h == 0: an image without rows -- the general path indexes it as the reference would)
+                rec[8 * (size_t)m + c] = desc;
+            }
+        if (sc->upload(rec.data(), rec.size(), &D.matRec, "matRec")) return -1;
+    }
     HIP_OK(sc->stager.drain());
     return 0;
 }

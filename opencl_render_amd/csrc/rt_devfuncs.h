@@ -251,10 +251,38 @@ __device__ __forceinline__ V3 texel(const RtDevScene &S, const Shared &sh, int s
     return mk(sh.unit255[px.x], sh.unit255[px.y], sh.unit255[px.z]);
 }
 
+// A material's channel descriptors (rt_device.h, matRec) in registers: two 16-byte loads issued together.
+struct MatRec { uint32_t desc[CH_COUNT]; int m; };
+__device__ __forceinline__ MatRec load_mat(const RtDevScene &S, int m)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(S.matRec + 8 * (size_t)m);
+    const uint4 a = p[0], b = p[1];
+    MatRec r;
+    r.desc[0] = a.x; r.desc[1] = a.y; r.desc[2] = a.z; r.desc[3] = a.w; r.desc[4] = b.x;
+    r.m = m;
+    return r;
+}
+// Get2dTableValue3 (raytrace_opencl.c:103-122) through the descriptor: a one-texel channel is answered from the descriptor itself
+// (u*(w-1) and v*(h-1) are 0 -- or NaN, which indexes texel 0 here -- whatever the uv), an image goes to the tables and the atlas.
+// Call only for a present channel (descriptor != 0).
+template <bool COUNT>
+__device__ __forceinline__ V3 texel_rec(const RtDevScene &S, const Shared &sh, const MatRec &M, int ch, const float *uv, float l1, float l2,
+                                        uint32_t &raw, Counters &cn)
+{
+    const uint32_t px = M.desc[ch];
+    if (px & 0x80000000u) {
+        if (COUNT) cn.v[ST_TEXELS]++;
+        raw = px & 255u;
+        return mk(sh.unit255[px & 255u], sh.unit255[(px >> 8) & 255u], sh.unit255[(px >> 16) & 255u]);
+    }
+    const int at = CH_COUNT * M.m + ch;
+    return texel<COUNT>(S, sh, S.matStart[at], S.matSize[2 * at], S.matSize[2 * at + 1], uv, l1, l2, raw, cn);
+}
+
 // ---- shading normal (raytrace_opencl.c:195-263) -----------------------------------------------------------------
 template <bool COUNT>
 __device__ V3 shading_normal(const RtDevScene &S, const Shared &sh, V3 where, V3 ray_o, V3 ray_d, uint32_t tri, float l1, float l2,
-                             const float *shade, int m, Counters &cn)
+                             const float *shade, int m, Counters &cn, const MatRec *mat = nullptr)
 {
     const float4 *rec = reinterpret_cast<const float4 *>(S.triRec) + 4 * (size_t)tri;
     const float4 r0 = rec[0];
@@ -271,16 +299,22 @@ __device__ V3 shading_normal(const RtDevScene &S, const Shared &sh, V3 where, V3
     n.z = (dab * nc.z + dbc * na.z + dca * nb.z) * inv;
 
     if (0 <= m) {
-        const uint32_t bw = S.matSize[2 * (CH_COUNT * m + CH_BUMP)];
+        const bool oneTexel = mat && (mat->desc[CH_BUMP] & 0x80000000u); // the height map is one texel, held in the descriptor
+        const uint32_t bw = oneTexel ? 1u : ((mat && mat->desc[CH_BUMP] == 0u) ? 0u : S.matSize[2 * (CH_COUNT * m + CH_BUMP)]);
         if (0 < bw) {
-            const uint32_t bh = S.matSize[2 * (CH_COUNT * m + CH_BUMP) + 1];
-            const int bstart = S.matStart[CH_COUNT * m + CH_BUMP];
+            const uint32_t bh = oneTexel ? 1u : S.matSize[2 * (CH_COUNT * m + CH_BUMP) + 1];
+            const int bstart = oneTexel ? 0 : S.matStart[CH_COUNT * m + CH_BUMP];
             const float *uv = shade + 15;
             const V3 tb = ld3(S.tb), lr = ld3(S.lr);
             uint32_t h0, hs, he;
             float t, p1 = 0.f, p2 = 0.f;
+            if (oneTexel) { // three fetches of the same texel
+                h0 = hs = he = mat->desc[CH_BUMP] & 255u;
+                if (COUNT) cn.v[ST_TEXELS] += 3;
+            } else
             (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, l1, l2, h0, cn);
-            if (bw == 1u && bh == 1u) { // one-texel height map: the neighbour samples are the same texel, wherever they land
+            if (oneTexel) {
+            } else if (bw == 1u && bh == 1u) { // one-texel height map: the neighbour samples are the same texel, wherever they land
                 (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, 0.f, 0.f, hs, cn);
                 (void)texel<COUNT>(S, sh, bstart, bw, bh, uv, 0.f, 0.f, he, cn);
             } else {

@@ -65,6 +65,12 @@ struct RtDevScene {
     const float *pairRec;
     // materials
     uint32_t materialCount, texelCount;
+    // matRec [M][8 words = 32 B]: one descriptor per channel (colour, reflection, transparency, bump, luminance), loaded in one
+    // burst when a hit is shaded instead of a chain of dependent loads per channel (size, then start, then texel):
+    //   0                      the channel is absent (0 x 0)
+    //   0x80000000 | b<<16|g<<8|r  a one-texel channel: the texel itself (what the reference's scenes are made of: render.cpp:1243-1275)
+    //   0x40000000             an image: size and start are read from matSize / matStart as before
+    const uint32_t *matRec;
     const uint32_t *matSize; // 2 x 5 per material
     const int32_t *matStart; // 5 per material
     const uint8_t *textures; // 4 bytes per texel

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         uint32_t rexcl = RT_NONE, laexcl = RT_NONE, a = 0;
 
         if (live) {
-            a = W.reqX[in][q].y;
+            a = (round == 0u) ? q : W.reqX[in][q].y; // (a path is born at its own round-0 queue index: one dependent load fewer)
             // round 0 consumes the primary hits (res); later rounds the keys the trace kernel left (hitKey), resolved below
             uint32_t res_tri = RT_NONE;
             float res_t = 0.f, res_l1 = 0.f, res_l2 = 0.f;
@@ -374,19 +374,19 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     const int m = __float_as_int(shade[21]);
                     const float *uv = shade + 15;
                     where = along(cur_o, hit_t, cur_d);
-                    n = shading_normal<false>(S, sh, where, cur_o, cur_d, hit_tri, hit_l1, hit_l2, shade, m, cn);
+                    // the material's whole record in one burst (rt_device.h, matRec): the channel look-ups below are then no chain
+                    // of dependent loads, and one-texel channels need no further load at all
+                    MatRec mat;
+                    mat.desc[0] = mat.desc[1] = mat.desc[2] = mat.desc[3] = mat.desc[4] = 0u; mat.m = m;
+                    if (0 <= m) mat = load_mat(S, m);
+                    n = shading_normal<false>(S, sh, where, cur_o, cur_d, hit_tri, hit_l1, hit_l2, shade, m, cn, &mat);
                     V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
                     if (0 <= m) {
-                        const int mc = CH_COUNT * m;
-                        uint32_t raw, w;
-                        w = S.matSize[2 * (mc + CH_COLOR)];
-                        if (0 < w) tex = texel<false>(S, sh, S.matStart[mc + CH_COLOR], w, S.matSize[2 * (mc + CH_COLOR) + 1], uv, hit_l1, hit_l2, raw, cn);
-                        w = S.matSize[2 * (mc + CH_TRANSPARENCY)];
-                        if (0 < w) transp = texel<false>(S, sh, S.matStart[mc + CH_TRANSPARENCY], w, S.matSize[2 * (mc + CH_TRANSPARENCY) + 1], uv, hit_l1, hit_l2, raw, cn);
-                        w = S.matSize[2 * (mc + CH_REFLECTION)];
-                        if (0 < w) refl = texel<false>(S, sh, S.matStart[mc + CH_REFLECTION], w, S.matSize[2 * (mc + CH_REFLECTION) + 1], uv, hit_l1, hit_l2, raw, cn);
-                        w = S.matSize[2 * (mc + CH_LUMINANCE)];
-                        if (0 < w) lum = texel<false>(S, sh, S.matStart[mc + CH_LUMINANCE], w, S.matSize[2 * (mc + CH_LUMINANCE) + 1], uv, hit_l1, hit_l2, raw, cn);
+                        uint32_t raw;
+                        if (mat.desc[CH_COLOR]) tex = texel_rec<false>(S, sh, mat, CH_COLOR, uv, hit_l1, hit_l2, raw, cn);
+                        if (mat.desc[CH_TRANSPARENCY]) transp = texel_rec<false>(S, sh, mat, CH_TRANSPARENCY, uv, hit_l1, hit_l2, raw, cn);
+                        if (mat.desc[CH_REFLECTION]) refl = texel_rec<false>(S, sh, mat, CH_REFLECTION, uv, hit_l1, hit_l2, raw, cn);
+                        if (mat.desc[CH_LUMINANCE]) lum = texel_rec<false>(S, sh, mat, CH_LUMINANCE, uv, hit_l1, hit_l2, raw, cn);
                     }
                     // :642-644 now (the light loop does not touch `out`), then the light-independent factors of :649-651
                     out.x += (1.f - out.x) * lum.x * cur_w.x;
@@ -489,9 +489,9 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                         const int om = __float_as_int(oshade[21]);
                         V3 tr = mk(0.f, 0.f, 0.f);
                         if (0 <= om) {
-                            const uint32_t w = S.matSize[2 * (CH_COUNT * om + CH_TRANSPARENCY)];
+                            const MatRec omat = load_mat(S, om);
                             uint32_t raw;
-                            if (0 < w) tr = texel<false>(S, sh, S.matStart[CH_COUNT * om + CH_TRANSPARENCY], w, S.matSize[2 * (CH_COUNT * om + CH_TRANSPARENCY) + 1], oshade + 15, res_l1, res_l2, raw, cn);
+                            if (omat.desc[CH_TRANSPARENCY]) tr = texel_rec<false>(S, sh, omat, CH_TRANSPARENCY, oshade + 15, res_l1, res_l2, raw, cn);
                         }
                         atten.x *= tr.x; atten.y *= tr.y; atten.z *= tr.z;
                         attStored = true;
