@@ -499,3 +499,23 @@ def test_device_detile_store_and_accumulate(name):
         rs.close()
         L.rtHipDeviceFree(0, planes)
         L.rtHipDeviceFree(0, ids)
+
+
+def test_planned_frames_with_several_sample_batches(monkeypatch):
+    """S=5 in batches of one or two samples: the launch plan is the maximum over the first frame's batches, a planned frame issues it
+    for every batch, the status kernel adds up what is left over all of them, and the ordered accumulate still sees the samples in
+    order (raytrace_opencl.c:726-741)."""
+    sc, want = load_golden_scene("sparse_many_samples")  # 80x60, S=5
+    for mb in ("20", "40"):
+        monkeypatch.setenv("RT_WF_STATE_MB", mb)
+        rs = R.ResidentScene(sc, 0)
+        try:
+            rs.render()
+            assert_planes(rs.readback(), want, f"watched frame, budget {mb} MB")
+            rs.render()
+            rs.render()
+            assert not rs.finish()
+            assert_planes(rs.readback(), want, f"planned frames, budget {mb} MB")
+        finally:
+            rs.close()
+    monkeypatch.delenv("RT_WF_STATE_MB")
