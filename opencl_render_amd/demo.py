@@ -1,8 +1,9 @@
-"""A small mesh scene for the front-end tests: a room of quads, a textured table, a pyramid of triangles and a sphere with
-smooth per-corner normals; one distant and one spot light.  Pure data (numpy), shared by the CPU and GPU tests."""
+"""A small mesh scene built through the headless front-end: a room of quads, a textured table, a pyramid of triangles and a
+sphere with smooth per-corner normals; one distant and one spot light.  Pure data (numpy); used by the command-line harness
+(``python -m opencl_render_amd``) and by the front-end tests."""
 import numpy as np
 
-from opencl_render_amd import frontend as F
+from . import frontend as F
 
 
 def quad_box(lo, hi, material, inward=False, open_front=False):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-import frontend_cases as FC
+from opencl_render_amd import demo as FC
 from opencl_render_amd import frontend as F, raytrace as R
 
 f32 = np.float32

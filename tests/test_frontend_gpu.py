@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-import frontend_cases as FC
+from opencl_render_amd import demo as FC
 import oracle_lib as O
 from opencl_render_amd import frontend as F, raytrace as R
 
@@ -31,3 +31,20 @@ def test_mesh_to_image_file_on_the_gpu(tmp_path, hip_lib):
         writer(want_path, *want)
         data = open(got_path, "rb").read()
         assert data == open(want_path, "rb").read() and len(data) > 200 * 150 * 3
+
+
+def test_command_line_harness_writes_the_image(tmp_path, hip_lib):
+    """python -m opencl_render_amd: the dialog's fields on a command line (render.cpp:174-186) -> scene, lists on the device,
+    RaytraceAll, image file."""
+    from opencl_render_amd import __main__ as cli
+    out = str(tmp_path / "room.bmp")
+    assert cli.main(["--scene", "room", "--width", "160", "--height", "120", "--samples", "4", "--out", out]) == 0
+    data = open(out, "rb").read()
+    assert data[:2] == b"BM" and len(data) == 54 + 160 * 120 * 3
+    sc = FC.room_scene(160, 120, samples=4)
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    want_path = str(tmp_path / "oracle.bmp")
+    F.write_bmp(want_path, *want)
+    assert data == open(want_path, "rb").read()
+    R.lib().rtHipCacheClear()
