@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void cam_dedup_compact(uint64_t P, const uint3
 }
 
 struct Buffers { // frees what it holds
-    void *p[16] = { nullptr };
+    void *p[24] = { nullptr };
     int n = 0;
     template <class T> hipError_t alloc(T **dst, size_t count)
     {
@@ -364,22 +364,93 @@ __global__ __launch_bounds__(256) void grid_fill_small(uint32_t T, const float4 
     for (uint32_t k = 0; k < n; ++k) keys[at + k] = ((unsigned long long)cells[k] << 32) | t;
 }
 
+// Cells whose closed interval [plane[i], plane[i+1]] meets [vmin, vmax] on one axis: first and last index.  A cell outside that
+// range lies strictly beyond the triangle on this axis, so the first clip against it removes every point (comparisons only, no
+// rounding): it cannot pass the box test.  (Planes may repeat -- zero-width cells -- which is why this is not "vertex cell +- 1".)
+__device__ __forceinline__ void overlap_range(const float (*bm)[4], int axis, float vmin, float vmax, int &first, int &last)
+{
+    int lo = 0, hi = rtbuild::DIV - 1;
+    while (lo < rtbuild::DIV - 1 && bm[lo + 1][axis] < vmin) ++lo;
+    while (hi > 0 && vmax < bm[hi][axis]) --hi;
+    first = lo; last = hi < lo ? lo : hi;
+}
+
+// Upper bound of the cells the big triangles can fill (their overlap boxes), so the key buffer can be sized before they are filled.
+__global__ __launch_bounds__(256) void grid_big_bound(const float4 *__restrict__ vertex, const int4 *__restrict__ triIndex, const float *__restrict__ bmGlobal,
+                                                      const uint32_t *__restrict__ bigList, const uint32_t *__restrict__ bigCount, unsigned long long *bound)
+{
+    __shared__ float bm[rtbuild::DIV + 1][4];
+    for (int i = threadIdx.x; i < 4 * (rtbuild::DIV + 1); i += 256) (&bm[0][0])[i] = bmGlobal[i];
+    __syncthreads();
+    for (uint32_t bidx = blockIdx.x * 256 + threadIdx.x; bidx < bigCount[0]; bidx += gridDim.x * 256) {
+        const int4 vi = triIndex[bigList[bidx]];
+        const F3 a = vtx(vertex, vi.x), b = vtx(vertex, vi.y), c = vtx(vertex, vi.z);
+        const float mn[3] = { fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)) };
+        const float mx[3] = { fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)) };
+        unsigned long long n = 1;
+        for (int w = 0; w < 3; ++w) { int f, l; overlap_range(bm, w, mn[w], mx[w], f, l); n *= (unsigned long long)(l - f + 1); }
+        atomicAdd(bound, n + 1ull); // + the cell of vertex a, which is taken untested
+    }
+}
+
+// Big triangles.  The fill finds the face-connected set of cells that pass the box test around the cell of vertex a (FillCube,
+// trianglelist.cpp:452-503).  The test of a cell does not depend on how the fill reached it, so every cell of a triangle's overlap
+// box is tested ONCE, by the whole GPU (grid_test_big: blockIdx.y = the triangle's slot in the current batch), into a per-slot bitmap;
+// the flood itself (grid_fill_big, one workgroup per triangle) then only follows bits, level by level.  (Testing inside the flood,
+// as the reference does, tests a cell once per already-filled neighbour and serialises ~700 levels of box tests for a wall-sized
+// triangle: 1 s for a 146-triangle room.)
+__global__ __launch_bounds__(256) void grid_test_big(const float4 *__restrict__ vertex, const int4 *__restrict__ triIndex, const float *__restrict__ bmGlobal,
+                                                     const uint32_t *__restrict__ bigList, uint32_t batchBase, uint32_t *passmaps)
+{
+    __shared__ float bm[rtbuild::DIV + 1][4];
+    __shared__ int range[6];
+    for (int i = threadIdx.x; i < 4 * (rtbuild::DIV + 1); i += 256) (&bm[0][0])[i] = bmGlobal[i];
+    __syncthreads();
+    const uint32_t t = bigList[batchBase + blockIdx.y];
+    uint32_t *pass = passmaps + (size_t)blockIdx.y * (GRID_CELLS / 32);
+    const int4 vi = triIndex[t];
+    const F3 a = vtx(vertex, vi.x), b = vtx(vertex, vi.y), c = vtx(vertex, vi.z);
+    if (threadIdx.x < 3) {
+        const int w = threadIdx.x;
+        const float va = w == 0 ? a.x : (w == 1 ? a.y : a.z), vb = w == 0 ? b.x : (w == 1 ? b.y : b.z), vc = w == 0 ? c.x : (w == 1 ? c.y : c.z);
+        overlap_range(bm, w, fminf(va, fminf(vb, vc)), fmaxf(va, fmaxf(vb, vc)), range[2 * w], range[2 * w + 1]);
+    }
+    __syncthreads();
+    const uint32_t nx = (uint32_t)(range[1] - range[0] + 1), ny = (uint32_t)(range[3] - range[2] + 1), nz = (uint32_t)(range[5] - range[4] + 1);
+    const unsigned long long boxCells = (unsigned long long)nx * ny * nz;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < boxCells; i += (unsigned long long)gridDim.x * 256) {
+        const int cx = range[0] + (int)(i % nx), cy = range[2] + (int)((i / nx) % ny), cz = range[4] + (int)(i / ((unsigned long long)nx * ny));
+        const float lo[3] = { bm[cx][0], bm[cy][1], bm[cz][2] }, hi[3] = { bm[cx + 1][0], bm[cy + 1][1], bm[cz + 1][2] };
+        if (rtbuild::box_hits_triangle(lo, hi, a, b, c)) {
+            const uint32_t id = (uint32_t)cx + (uint32_t)cy * rtbuild::DIV + (uint32_t)cz * rtbuild::DIV * rtbuild::DIV;
+            atomicOr(&pass[id >> 5], 1u << (id & 31));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void grid_fill_big(const float4 *__restrict__ vertex, const int4 *__restrict__ triIndex, const float *__restrict__ bmGlobal,
                                                      unsigned long long *keys, unsigned long long *keyCursor, unsigned long long keyCap,
-                                                     const uint32_t *__restrict__ bigList, const uint32_t *__restrict__ bigCount, uint32_t *bitmaps,
-                                                     uint32_t *queues, uint32_t *overflow)
+                                                     const uint32_t *__restrict__ bigList, uint32_t batchBase, uint32_t *bitmaps,
+                                                     uint32_t *passmaps, uint32_t *queues, uint32_t *overflow)
 {
     __shared__ float bm[rtbuild::DIV + 1][4];
     __shared__ uint32_t qCount, levelStart, levelEnd;
     __shared__ unsigned long long keyBase;
+    __shared__ int range[6];
     for (int i = threadIdx.x; i < 4 * (rtbuild::DIV + 1); i += 256) (&bm[0][0])[i] = bmGlobal[i];
     uint32_t *bits = bitmaps + (size_t)blockIdx.x * (GRID_CELLS / 32); // all zero between triangles
+    uint32_t *pass = passmaps + (size_t)blockIdx.x * (GRID_CELLS / 32); // this slot's test results (grid_test_big); cleared at the end
     uint32_t *queue = queues + (size_t)blockIdx.x * RT_FILL_QUEUE;
     __syncthreads();
-    for (uint32_t bidx = blockIdx.x; bidx < bigCount[0]; bidx += gridDim.x) {
-        const uint32_t t = bigList[bidx];
+    {
+        const uint32_t t = bigList[batchBase + blockIdx.x];
         const int4 vi = triIndex[t];
         const F3 a = vtx(vertex, vi.x), b = vtx(vertex, vi.y), c = vtx(vertex, vi.z);
+        if (threadIdx.x < 3) {
+            const int w = threadIdx.x;
+            const float va = w == 0 ? a.x : (w == 1 ? a.y : a.z), vb = w == 0 ? b.x : (w == 1 ? b.y : b.z), vc = w == 0 ? c.x : (w == 1 ? c.y : c.z);
+            overlap_range(bm, w, fminf(va, fminf(vb, vc)), fmaxf(va, fmaxf(vb, vc)), range[2 * w], range[2 * w + 1]);
+        }
         if (threadIdx.x == 0) {
             int cell[3];
             rtbuild::box_address(bm, a, cell);
@@ -389,31 +460,26 @@ __global__ __launch_bounds__(256) void grid_fill_big(const float4 *__restrict__ 
             qCount = 1; levelStart = 0; levelEnd = 1;
         }
         __syncthreads();
+        const uint32_t nx = (uint32_t)(range[1] - range[0] + 1), ny = (uint32_t)(range[3] - range[2] + 1), nz = (uint32_t)(range[5] - range[4] + 1);
+        const unsigned long long boxCells = (unsigned long long)nx * ny * nz;
         while (levelStart < levelEnd) { // workgroup-uniform
             for (uint32_t q = levelStart + threadIdx.x; q < levelEnd; q += 256) {
                 const uint32_t id = queue[q];
                 int cell[3] = { (int)(id % rtbuild::DIV), (int)((id % (rtbuild::DIV * rtbuild::DIV)) / rtbuild::DIV), (int)(id / (rtbuild::DIV * rtbuild::DIV)) };
-                float lo[3], hi[3];
-                for (int i = 0; i < 3; ++i) { lo[i] = bm[cell[i]][i]; hi[i] = bm[cell[i] + 1][i]; }
                 for (int i = 0; i < 3; ++i) {
                     for (int j = -1; j <= 1; j += 2) {
                         cell[i] += j;
                         if (0 <= cell[i] && cell[i] < rtbuild::DIV) {
                             const uint32_t nid = (uint32_t)cell[0] + (uint32_t)cell[1] * rtbuild::DIV + (uint32_t)cell[2] * rtbuild::DIV * rtbuild::DIV;
                             const uint32_t mask = 1u << (nid & 31);
-                            if (!(__atomic_load_n(&bits[nid >> 5], __ATOMIC_RELAXED) & mask)) {
-                                lo[i] = bm[cell[i]][i];
-                                hi[i] = bm[cell[i] + 1][i];
-                                if (rtbuild::box_hits_triangle(lo, hi, a, b, c) && !(atomicOr(&bits[nid >> 5], mask) & mask)) {
-                                    const uint32_t pos = atomicAdd(&qCount, 1u);
-                                    if (pos < RT_FILL_QUEUE) queue[pos] = nid; else atomicExch(overflow, 2u);
-                                }
+                            if ((__atomic_load_n(&pass[nid >> 5], __ATOMIC_RELAXED) & mask) && !(__atomic_load_n(&bits[nid >> 5], __ATOMIC_RELAXED) & mask) &&
+                                !(atomicOr(&bits[nid >> 5], mask) & mask)) {
+                                const uint32_t pos = atomicAdd(&qCount, 1u);
+                                if (pos < RT_FILL_QUEUE) queue[pos] = nid; else atomicExch(overflow, 2u);
                             }
                         }
                         cell[i] -= j;
                     }
-                    lo[i] = bm[cell[i]][i];
-                    hi[i] = bm[cell[i] + 1][i];
                 }
             }
             __threadfence_block();
@@ -431,7 +497,10 @@ __global__ __launch_bounds__(256) void grid_fill_big(const float4 *__restrict__ 
             if (fits) keys[keyBase + q] = ((unsigned long long)id << 32) | t;
             bits[id >> 5] = 0u; // clear what this triangle set (a word may be cleared by several threads)
         }
-        __syncthreads();
+        for (unsigned long long i = threadIdx.x; i < boxCells; i += 256) { // and the test results (a word may be cleared repeatedly)
+            const uint32_t cx = (uint32_t)range[0] + (uint32_t)(i % nx), cy = (uint32_t)range[2] + (uint32_t)((i / nx) % ny), cz = (uint32_t)range[4] + (uint32_t)(i / ((unsigned long long)nx * ny));
+            pass[(cx + cy * rtbuild::DIV + cz * rtbuild::DIV * rtbuild::DIV) >> 5] = 0u;
+        }
     }
 }
 
@@ -500,17 +569,39 @@ extern "C" int rtHipBuildSceneGridDevice(int device, cl_uint vertexCount, cl_uin
     uint32_t overflow = 0;
     Buffers bufRetry;
     unsigned long long cap = keyCap;
+    uint32_t *dPassmaps = nullptr;
+    unsigned long long *dBound = nullptr;
+    BUILD_OK(buf3.alloc(&dPassmaps, (size_t)RT_FILL_GROUPS * (GRID_CELLS / 32))); BUILD_OK(buf3.alloc(&dBound, 1));
+    BUILD_OK(hipMemsetAsync(dPassmaps, 0, (size_t)RT_FILL_GROUPS * (GRID_CELLS / 32) * 4, nullptr));
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (T) {
             hipLaunchKernelGGL(grid_fill_small, dim3((T + 255) / 256), dim3(256), 0, nullptr, T, dVertex, dIndex, dBm, dKeys, dCursor, cap, dBigList,
                                dBigCount, dOverflow);
-            hipLaunchKernelGGL(grid_fill_big, dim3(RT_FILL_GROUPS), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dKeys, dCursor, cap, dBigList, dBigCount,
-                               dBitmaps, dQueues, dOverflow);
+            // the big triangles' cells are bounded by their overlap boxes: make room for them before they are filled
+            BUILD_OK(hipMemsetAsync(dBound, 0, 8, nullptr));
+            hipLaunchKernelGGL(grid_big_bound, dim3(64), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dBigList, dBigCount, dBound);
+            unsigned long long small = 0, bound = 0;
+            BUILD_OK(hipMemcpy(&small, dCursor, 8, hipMemcpyDeviceToHost));
+            BUILD_OK(hipMemcpy(&bound, dBound, 8, hipMemcpyDeviceToHost));
+            if (small <= cap && small + bound > cap && small + bound <= (1ull << 31)) {
+                unsigned long long *bigger = nullptr, *biggerSorted = nullptr;
+                BUILD_OK(bufRetry.alloc(&bigger, (size_t)(small + bound))); BUILD_OK(bufRetry.alloc(&biggerSorted, (size_t)(small + bound)));
+                if (small) BUILD_OK(hipMemcpy(bigger, dKeys, (size_t)small * 8, hipMemcpyDeviceToDevice));
+                dKeys = bigger; dKeysSorted = biggerSorted; cap = small + bound;
+            }
+            uint32_t bigTotal = 0;
+            BUILD_OK(hipMemcpy(&bigTotal, dBigCount, 4, hipMemcpyDeviceToHost));
+            for (uint32_t base = 0; base < bigTotal; base += RT_FILL_GROUPS) { // RT_FILL_GROUPS bitmaps: that many big triangles at a time
+                const uint32_t batch = std::min<uint32_t>(RT_FILL_GROUPS, bigTotal - base);
+                hipLaunchKernelGGL(grid_test_big, dim3(128, batch), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dBigList, base, dPassmaps);
+                hipLaunchKernelGGL(grid_fill_big, dim3(batch), dim3(256), 0, nullptr, dVertex, dIndex, dBm, dKeys, dCursor, cap, dBigList, base,
+                                   dBitmaps, dPassmaps, dQueues, dOverflow);
+            }
         }
         BUILD_OK(hipMemcpy(&n, dCursor, 8, hipMemcpyDeviceToHost));
         BUILD_OK(hipMemcpy(&overflow, dOverflow, 4, hipMemcpyDeviceToHost));
         if (overflow != 1u || attempt == 1) break;
-        // More pairs than the key buffer holds (a few huge triangles: walls, floors).  The cursor has counted them all, like
+        // More pairs than the key buffer holds after all (very many mid-sized triangles).  The cursor has counted them all, like
         // the reference's own overflow pass (trianglelist.cpp:696-706): fill again into a buffer of exactly that size.
         if (n > 0xffffffffull) return -3;
         cap = n;
