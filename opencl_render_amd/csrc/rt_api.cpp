@@ -36,7 +36,7 @@ extern "C" hipError_t rtp_validate(uint32_t T, uint32_t V, uint32_t M, const voi
 extern "C" hipError_t rtp_camera_ranges(uint32_t W, uint32_t H, uint32_t tilesX, const uint32_t *tileIds, uint32_t tileCount, const uint32_t *camStart,
                                         const uint32_t *camEnd, uint64_t camListSize, uint32_t *outStart, uint32_t *outEnd, uint32_t *err, hipStream_t stream);
 extern "C" hipError_t rtp_dense_grid(const uint32_t *gridStart, const uint32_t *gridList, unsigned long long *words, uint32_t *sparse, uint32_t *pairOrder,
-                                     uint32_t *pairCount, uint32_t *cellRest, void *scratch, size_t *scratchBytes, hipStream_t stream);
+                                     uint32_t *pairCount, void *scratch, size_t *scratchBytes, hipStream_t stream);
 
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
@@ -392,24 +392,23 @@ int build_grid(rtHipScene *sc, const rtHipSceneDesc *d)
     if (sc->check_prep() != 0) return -1; // the dense view walks the lists through the starts
     const size_t blocks = (size_t)(RT_GRID_DIV / 4) * (RT_GRID_DIV / 4) * (RT_GRID_DIV / 4);
     unsigned long long *words = nullptr;
-    uint32_t *sparse = nullptr, *cellRest = nullptr;
+    uint32_t *sparse = nullptr;
     const size_t sparseWords = (size_t)3 * ((63u << 16 | 63u << 8 | 63u) + 1u);
-    if (sc->alloc<unsigned long long>(blocks, &words) || sc->alloc<uint32_t>(sparseWords, &sparse) ||
-        sc->alloc<uint32_t>(std::min<uint64_t>(listSize, cells), &cellRest))
-        return -1;
+    if (listSize >= RT_PAIR_LIMIT) return fail("scenePixelTriangleList has 2^28 entries or more: pair indices would not fit the trace kernel's records");
+    if (sc->alloc<unsigned long long>(blocks, &words) || sc->alloc<uint32_t>(sparseWords, &sparse)) return -1;
     HIP_OK(hipMemsetAsync(sparse, 0, sparseWords * 4, sc->stream));
     DevScratch scratch;
     uint32_t *pairOrder = nullptr, *pairCount = nullptr;
     void *tmp = nullptr;
     size_t tmpBytes = 0;
-    HIP_OK(rtp_dense_grid(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tmpBytes, sc->stream));
+    HIP_OK(rtp_dense_grid(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tmpBytes, sc->stream));
     HIP_OK(scratch.get((void **)&pairOrder, (size_t)listSize * 4)); HIP_OK(scratch.get((void **)&pairCount, (size_t)listSize * 4));
     HIP_OK(scratch.get(&tmp, tmpBytes));
-    HIP_OK(rtp_dense_grid(D.gridStart, D.gridList, words, sparse, pairOrder, pairCount, cellRest, tmp, &tmpBytes, sc->stream));
+    HIP_OK(rtp_dense_grid(D.gridStart, D.gridList, words, sparse, pairOrder, pairCount, tmp, &tmpBytes, sc->stream));
     float *pairRec = nullptr;
     if (sc->alloc<float>((uint64_t)listSize * 16, &pairRec)) return -1;
     HIP_OK(rtk_launch_gather_pairs((uint32_t)listSize, pairOrder, pairCount, D.triRec, pairRec, sc->stream));
-    D.gridBits = words; D.gridBlockSparse = sparse; D.cellRest = cellRest; D.pairRec = pairRec;
+    D.gridBits = words; D.gridBlockSparse = sparse; D.pairRec = pairRec;
     D.cellCount = 0; // informational; the kernels find a cell's records through the block table
     HIP_OK(hipStreamSynchronize(sc->stream));
     return 0;

@@ -57,10 +57,11 @@ struct RtDevScene {
     //                     dependent gather (the typical cell of a fine scene holds one triangle), where a {first, last} range
     //                     table in between cost a second 128-byte fabric request per visit (profiles/r02_*: the trace kernel
     //                     runs at ~90 % of the chip's L2-miss request rate, two requests per occupied cell).  The further
-    //                     candidates of cell k, in list order, sit at cellRest[k] .. cellRest[k] + count - 2 (records
-    //                     [cellCount, pairs), `count` field unused).
+    //                     candidates of cell k, in list order, sit at rest .. rest + count - 2 (records [cellCount, pairs)).
+    //                     The first record's `count` word is min(count, RT_PAIR_MANY) | rest << 4; a cell with RT_PAIR_MANY
+    //                     or more candidates has its exact count in the `count` word of its first FURTHER record.  Pair
+    //                     indices therefore stay below 2^28 (build_grid refuses larger scenes: 17 GB of records).
     const uint32_t *gridBlockSparse;
-    const uint32_t *cellRest;
     uint32_t cellCount; // non-empty cells
     const float *pairRec;
     // materials
@@ -116,6 +117,8 @@ struct RtDevScene {
                                // host last cleared it: non-zero = the frame is INCOMPLETE (the planned number of rounds was too small)
 #define RT_WF_STATUS_BATCHES 2 // batches whose issued rounds are over (a progress count for the host)
 #define RT_WF_STATUS_WORDS 16
+#define RT_PAIR_MANY 15u            // a first pair record's count field saturates here (rt_device.h, pairRec)
+#define RT_PAIR_LIMIT (1u << 28)    // pair indices must fit the record's rest field and the trace kernel's 29-bit key field
 #define RT_WF_ROUND_LOG 64     // rounds of a batch whose trace-input size is logged for the launch plan (RtWavefront::roundLog)
 #define RT_WF_ERR_SPIN 1u     // wf_trace_kernel's walk guard tripped: rays were abandoned, the frame is invalid
 #define RT_WF_ERR_GRID 2u     // a planned frame's trace grid was smaller than the round's entries: entries were not traced; the host renders

@@ -4,8 +4,8 @@
 //     starts) -- a bad id would be an out-of-bounds gather; the reference does no such check (raytrace.c:344-489);
 //   * the tile-major view of the per-pixel candidate ranges (index slot*128*128 + ly*128 + lx) for this instance's tiles;
 //   * the dense view of the 256^3 grid for the wavefront trace kernel (rt_device.h): occupancy word and rank per 4x4x4 block,
-//     pair order "first candidate of every non-empty cell at its dense id, then everybody's further candidates", the
-//     sparsely indexed block table.
+//     pair order "first candidate of every non-empty cell at its dense id, then everybody's further candidates" with the
+//     word each first record carries about its cell, the sparsely indexed block table.
 // Each is a stream kernel over arrays that are in HBM anyway (67 MB of grid starts, the lists); on the host they were
 // single-threaded loops of 30-100 ms per scene at 1 M triangles.
 #include <hip/hip_runtime.h>
@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void rtp_block_words(const uint32_t *__restric
 __global__ __launch_bounds__(256) void rtp_block_emit(const uint32_t *__restrict__ gridStart, const uint32_t *__restrict__ gridList,
                                                       const unsigned long long *__restrict__ words, const uint32_t *__restrict__ rank,
                                                       const uint32_t *__restrict__ restBase, const uint32_t *__restrict__ blockCells,
-                                                      uint32_t *__restrict__ sparse, uint32_t *__restrict__ pairOrder, uint32_t *__restrict__ pairCount,
-                                                      uint32_t *__restrict__ cellRest)
+                                                      uint32_t *__restrict__ sparse, uint32_t *__restrict__ pairOrder, uint32_t *__restrict__ pairCount)
 {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     const uint32_t bx = b & 63u, by = (b >> 6) & 63u, bz = b >> 12;
@@ -108,9 +107,10 @@ __global__ __launch_bounds__(256) void rtp_block_emit(const uint32_t *__restrict
         const uint32_t cell = (bx * 4 + (bit & 3)) + RT_GRID_DIV * (by * 4 + ((bit >> 2) & 3)) + RT_GRID_DIV * RT_GRID_DIV * (bz * 4 + (bit >> 4));
         const uint32_t s = gridStart[cell], n = gridStart[cell + 1] - s;
         pairOrder[dense] = gridList[s];
-        pairCount[dense] = n;
-        cellRest[dense] = restAt;
-        for (uint32_t i = 1; i < n; ++i) { pairOrder[restAt] = gridList[s + i]; pairCount[restAt] = 0u; ++restAt; }
+        // what the first record says about its cell: candidates (15 = "15 or more") | where the further ones start << 4
+        pairCount[dense] = (n < RT_PAIR_MANY ? n : RT_PAIR_MANY) | (restAt << 4);
+        // the first of the further records carries the exact count (read only for cells with RT_PAIR_MANY or more)
+        for (uint32_t i = 1; i < n; ++i) { pairOrder[restAt] = gridList[s + i]; pairCount[restAt] = (i == 1u) ? n : 0u; ++restAt; }
         ++dense;
     }
 }
@@ -139,7 +139,7 @@ extern "C" hipError_t rtp_camera_ranges(uint32_t W, uint32_t H, uint32_t tilesX,
 
 // scratch: 4 x BLOCKS u32 + the scan's temporary storage; `scanBytes` in/out like hipcub (call with scratch == nullptr to size it)
 extern "C" hipError_t rtp_dense_grid(const uint32_t *gridStart, const uint32_t *gridList, unsigned long long *words, uint32_t *sparse, uint32_t *pairOrder,
-                                     uint32_t *pairCount, uint32_t *cellRest, void *scratch, size_t *scratchBytes, hipStream_t stream)
+                                     uint32_t *pairCount, void *scratch, size_t *scratchBytes, hipStream_t stream)
 {
     size_t scanBytes = 0;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)BLOCKS, stream);
@@ -155,6 +155,6 @@ extern "C" hipError_t rtp_dense_grid(const uint32_t *gridStart, const uint32_t *
     e = hipcub::DeviceScan::ExclusiveSum(scanTmp, scanBytes, blockRest, restBase, (int)BLOCKS, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rtp_block_emit, dim3(BLOCKS / 256), dim3(256), 0, stream, gridStart, gridList, words, rank, restBase, blockCells, sparse, pairOrder,
-                       pairCount, cellRest);
+                       pairCount);
     return hipGetLastError();
 }

@@ -158,6 +158,12 @@ __device__ __forceinline__ uint32_t resolve_hit(const RtDevScene &S, unsigned lo
     return __float_as_uint(r0.w);
 }
 
+// Order of the hits of one ray inside a test phase: earlier recorded cell, then smaller t, then earlier candidate.
+__device__ __forceinline__ unsigned long long hit_key(uint32_t cellOrder, float t, uint32_t pair)
+{
+    return ((unsigned long long)cellOrder << 60) | ((unsigned long long)__float_as_uint(t) << 29) | (unsigned long long)pair;
+}
+
 #ifdef RT_DIAG_STAMPS
 // Diagnostic build only (never shipped, outputs untouched): shader-clock stamps, summed per wave into S.stats.
 __device__ __forceinline__ unsigned long long diag_stamp()
@@ -985,6 +991,9 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 #ifndef RT_WF_BLIND
 #define RT_WF_BLIND 8                 // cell visits per blind phase
 #endif
+#ifndef RT_WF_MORE_ITEMS
+#define RT_WF_MORE_ITEMS 128          // per-wave list of further candidates (beyond a cell's first) awaiting their test
+#endif
 #ifndef RT_WF_LEAN_STALL
 #define RT_WF_LEAN_STALL 64           // test once (lanes without room for another phase) x this exceeds the lanes still walking
 #endif
@@ -993,7 +1002,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t cellList[RT_WF_LEAN_LIST][256];                 // [entry][thread] packed cells cx | cy<<8 | cz<<16
     __shared__ uint8_t ownerOf[4][RT_WF_LEAN_LIST * 64];                // per wave: lane that recorded item c
-    __shared__ unsigned long long keyOf[4][64];                         // per wave and lane: (cell order, pair index) of the earliest hit
+    __shared__ unsigned long long keyOf[4][64];                         // per wave and lane: (cell order, t, pair index) of the earliest hit
+    __shared__ uint32_t moreOf[4][2][RT_WF_MORE_ITEMS];                 // per wave: further candidates under test {owner | cell order << 6}, {pair}
+    __shared__ uint32_t moreCount[4];
+    static_assert(RT_WF_LEAN_LIST <= 16, "hit_key: 4 bits of cell order");
 
     // entries [0, total) and -- in an appended round -- the extra segments in region B, which follow in 64-entry chunks
     const uint32_t total = W.sortTotal[0];
@@ -1150,9 +1162,15 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         dgWalk += dgT0 - dgW0;
         dgBatches++;
 #endif
-        // ---- test, wave-cooperative: items = recorded cells of the whole wave, one per lane and round.  A cell's candidates
-        // are tested with the reference's running maximum (:366-379); the owner's answer is the hit of its EARLIEST cell
-        // (:380), found with an LDS atomicMin on (cell order, pair index); the owner then re-evaluates that one pair.
+        // ---- test, wave-cooperative: items = recorded cells of the whole wave, one per lane and round.  The reference tests a
+        // cell's candidates in list order against a running maximum that is reset per cell (:366-379) and takes the hit of the
+        // EARLIEST cell that has one (:380).  A candidate's own t, l1, l2 do not depend on the running maximum -- it only picks
+        // the smallest t, the earlier candidate on a tie -- so candidates are tested independently and an LDS atomicMin on
+        // (cell order | t | pair index) finds the same winner (t > tmin >= 0: its bits order like the value; pair indices grow
+        // in list order inside a cell).  Round one tests every cell's FIRST candidate (it sits at the cell's dense id and says
+        // how many more there are and where), the further candidates of all cells are flattened into a second list and tested
+        // one per lane afterwards (7 % of the cells of a fine scene have any: looping over them cell by cell ran 64-lane
+        // instructions for a handful of lanes, behind two more dependent gathers).  The owner re-evaluates the winning pair.
         {
             wordKey = 0xffffffffu; // the cached occupancy word is not carried across the test phase (three registers at the kernel's peak)
             const uint32_t mineN = listed;
@@ -1170,8 +1188,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
             if (items) { // wave-uniform
                 volatile uint8_t *owners = ownerOf[wave];
                 volatile unsigned long long *keys = keyOf[wave];
+                volatile uint32_t *moreWho = moreOf[wave][0], *morePair = moreOf[wave][1];
                 for (uint32_t j = 0; j < mineN; ++j) owners[myBase + j] = (uint8_t)lane;
                 keys[lane] = ~0ull;
+                if (lane == 0) moreCount[wave] = 0u;
                 __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
                 for (uint32_t c0 = 0; c0 < items; c0 += 64) {
                     const uint32_t c = c0 + lane;
@@ -1191,35 +1211,60 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                         const uint32_t bit = (pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u);
                         const unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;
                         const uint32_t dense = rank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
-                        uint32_t bestPair = RT_NONE;
-                        float tbest = ptmax; // running maximum, reset per cell (:366)
-                        // the cell's first candidate sits at the dense id itself (rt_device.h, pairRec) and says how many there are
                         const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)dense;
                         float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                        const uint32_t count = __float_as_uint(r1.w);
-                        {
-                            float t, l1, l2;
-                            if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, tbest, pexcl, t, l1, l2)) { bestPair = dense; tbest = t; }
-                        }
-                        if (count > 1u) { // further candidates, in list order (rare in a fine scene: no prefetch, registers matter more)
-                            const uint32_t restAt = S.cellRest[dense];
-                            rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)restAt;
-#pragma unroll 1
-                            for (uint32_t i = 0; i + 1 < count; ++i, rec += 4) {
+                        const uint32_t info = __float_as_uint(r1.w);
+                        unsigned long long best = ~0ull;
+                        float t, l1, l2;
+                        if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, ptmax, pexcl, t, l1, l2)) best = hit_key(j, t, dense);
+                        uint32_t n = info & 15u;
+                        if (n > 1u) { // further candidates: onto the second list; a crowded cell, or one the list has no room for, in place
+                            uint32_t restAt = info >> 4, i = 0;
+                            if (n < RT_PAIR_MANY) {
+                                const uint32_t at = atomicAdd(&moreCount[wave], n - 1u);
+                                for (; i + 1 < n && at + i < RT_WF_MORE_ITEMS; ++i) { moreWho[at + i] = owner | (j << 6); morePair[at + i] = restAt + i; }
+                            }
+                            if (i + 1 < n) {
+                                rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)(restAt + i);
                                 r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
-                                float t, l1, l2;
-                                if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, tbest, pexcl, t, l1, l2)) { bestPair = restAt + i; tbest = t; }
+                                if (n == RT_PAIR_MANY) n = __float_as_uint(r1.w); // (i == 0 here: the first further record has the exact count)
+#pragma unroll 1
+                                for (;;) {
+                                    if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, ptmax, pexcl, t, l1, l2)) best = min(best, hit_key(j, t, restAt + i));
+                                    if (++i + 1 >= n) break;
+                                    rec += 4;
+                                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+                                }
                             }
                         }
-                        if (bestPair != RT_NONE)
-                            atomicMin((unsigned long long *)&keys[owner], ((unsigned long long)j << 32) | (unsigned long long)bestPair);
+                        if (best != ~0ull) atomicMin((unsigned long long *)&keys[owner], best);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t more = min(moreCount[wave], (uint32_t)RT_WF_MORE_ITEMS);
+                for (uint32_t e0 = 0; e0 < more; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    const bool has = e < more;
+                    const uint32_t who = has ? moreWho[e] : 0u;
+                    const uint32_t owner = who & 63u;
+                    const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+                    const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+                    const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64);
+                    const uint32_t pexcl = __shfl(excluded, owner, 64);
+                    if (has) {
+                        const uint32_t pair = morePair[e];
+                        const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)pair;
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                        float t, l1, l2;
+                        if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, ptmax, pexcl, t, l1, l2))
+                            atomicMin((unsigned long long *)&keys[owner], hit_key(who >> 6, t, pair));
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (mineN) {
                     const unsigned long long key = keys[lane];
                     if (key != ~0ull) { // this segment's hit: the ray's answer is that of its lowest segment with one
-                        atomicMin(&W.hitKey[q], ((unsigned long long)seg << 32) | (key & 0xffffffffull));
+                        atomicMin(&W.hitKey[q], ((unsigned long long)seg << 32) | (key & (unsigned long long)(2u * RT_PAIR_LIMIT - 1u)));
                         active = false;
                         walkEnded = true;
                     }
