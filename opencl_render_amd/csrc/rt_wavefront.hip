@@ -53,6 +53,19 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Two appends in one round trip: lanes 0 and 1 carry the two atomics of the wave in the same instruction.
+__device__ __forceinline__ void wave_append2(uint32_t *counterA, bool wantA, uint32_t *counterB, bool wantB, uint32_t &posA, uint32_t &posB)
+{
+    const unsigned long long maskA = __ballot(wantA), maskB = __ballot(wantB);
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    const uint32_t n = (lane == 0u) ? (uint32_t)__popcll(maskA) : (uint32_t)__popcll(maskB);
+    if (lane < 2u && n != 0u) base = atomicAdd(lane == 0u ? counterA : counterB, n);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    posA = (uint32_t)__shfl((int)base, 0, 64) + (uint32_t)__popcll(maskA & below);
+    posB = (uint32_t)__shfl((int)base, 1, 64) + (uint32_t)__popcll(maskB & below);
+}
+
 // Triangle test on a per-triangle record that is already in registers (rt_device.h: a | ab | ac | n | abab abac acac inv),
 // branch-free like pair_test_flat below: same operations and operands as tri_test for every lane whose plane distance is in
 // range, the others discard the second half.
@@ -164,7 +177,7 @@ __device__ __forceinline__ unsigned long long hit_key(uint32_t cellOrder, float 
     return ((unsigned long long)cellOrder << 60) | ((unsigned long long)__float_as_uint(t) << 29) | (unsigned long long)pair;
 }
 
-#ifdef RT_DIAG_STAMPS
+#if defined(RT_DIAG_STAMPS) || defined(RT_DIAG_LOGIC)
 // Diagnostic build only (never shipped, outputs untouched): shader-clock stamps, summed per wave into S.stats.
 __device__ __forceinline__ unsigned long long diag_stamp()
 {
@@ -266,11 +279,32 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 #ifndef RT_WF_LOGIC_WAVES
 #define RT_WF_LOGIC_WAVES 3
 #endif
+#define RT_WF_LIGHTS_LDS 64
 __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
 {
     __shared__ Shared sh; // only the texel/255 table is used here
+    // the first RT_WF_LIGHTS_LDS lights, one LDS read away instead of a chain of small global loads per light and state
+    __shared__ float4 ltPosRadius[RT_WF_LIGHTS_LDS], ltDirSpread[RT_WF_LIGHTS_LDS], ltColHalf[RT_WF_LIGHTS_LDS];
+    __shared__ int ltType[RT_WF_LIGHTS_LDS];
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
+    if (threadIdx.x < RT_WF_LIGHTS_LDS && threadIdx.x < S.lightCount) {
+        const uint32_t k = threadIdx.x;
+        ltType[k] = S.lightType[k];
+        ltPosRadius[k] = make_float4(S.lightPos[4 * k], S.lightPos[4 * k + 1], S.lightPos[4 * k + 2], S.lightRadius[k]);
+        ltDirSpread[k] = make_float4(S.lightDir[4 * k], S.lightDir[4 * k + 1], S.lightDir[4 * k + 2], S.lightSpread[k]);
+        ltColHalf[k] = make_float4(S.lightCol[4 * k], S.lightCol[4 * k + 1], S.lightCol[4 * k + 2], S.lightHalfAtt[k]);
+    }
     __syncthreads();
+    auto light_type = [&](uint32_t k) -> int { return k < RT_WF_LIGHTS_LDS ? ltType[k] : S.lightType[k]; };
+    auto light_pos_radius = [&](uint32_t k) -> float4 {
+        return k < RT_WF_LIGHTS_LDS ? ltPosRadius[k] : make_float4(S.lightPos[4 * k], S.lightPos[4 * k + 1], S.lightPos[4 * k + 2], S.lightRadius[k]);
+    };
+    auto light_dir_spread = [&](uint32_t k) -> float4 {
+        return k < RT_WF_LIGHTS_LDS ? ltDirSpread[k] : make_float4(S.lightDir[4 * k], S.lightDir[4 * k + 1], S.lightDir[4 * k + 2], S.lightSpread[k]);
+    };
+    auto light_col_half = [&](uint32_t k) -> float4 {
+        return k < RT_WF_LIGHTS_LDS ? ltColHalf[k] : make_float4(S.lightCol[4 * k], S.lightCol[4 * k + 1], S.lightCol[4 * k + 2], S.lightHalfAtt[k]);
+    };
 
     const uint32_t in = round & 1, outq = in ^ 1;
     const uint32_t *countIn = W.counts + (round % 3) * RT_WF_QSHARDS;
@@ -303,6 +337,10 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         if (localChunk * 64 >= total) continue; // wave-uniform
         const uint32_t q = shard * W.shardCap + local;
         const bool live = local < total;
+#ifdef RT_DIAG_LOGIC
+        const unsigned long long dg0 = diag_stamp();
+        unsigned long long dg1 = dg0, dg2 = dg0;
+#endif
         bool emit = false, emitLa = false;
         V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), lo3 = mk(0, 0, 0), ld3v = mk(0, 0, 0);
         float rtmin = 0.f, rtmax = 0.f, latmin = 0.f;
@@ -369,6 +407,10 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             }
             bool finished = false, shadedNow = false, rngDirty = false, outDirty = false;
             uint32_t emitStage = WS_RAY;
+#ifdef RT_DIAG_LOGIC
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dg1 = diag_stamp();
+#endif
 
             while (pc != PC_EXIT) {
                 if (pc == PC_RAY_RESULT) {
@@ -408,7 +450,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     // draws now: keep light 0's, remember where light 1's start, and leave the generator behind them all.
                     rngL = rng;
                     for (uint32_t k = 0; k < S.lightCount; ++k) {
-                        const int type = S.lightType[k];
+                        const int type = light_type(k);
                         if (type >= 1 && type <= 9) {
                             const SphereRaw rr = sphere_raw(rng);
                             if (k == 0) raw0 = rr;
@@ -461,23 +503,23 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     if (j >= S.lightCount) { pc = PC_SHADE_END; continue; }
                     toL = mk(0.f, 0.f, 0.f); atten = mk(1.f, 1.f, 1.f); attStored = false;
                     lmin = 0.f; lmax = 0.f;
-                    const int type = S.lightType[j];
+                    const int type = light_type(j);
                     if (type >= 1 && type <= 9) {
                         // light 0 is only ever set up in the invocation that shaded the hit, where its draws are at hand
                         const SphereRaw rr = (j == 0u) ? raw0 : sphere_raw(rngL);
                         if (type >= 3 && type <= 6) {
-                            const float *ld = S.lightDir + 4 * j;
-                            toL = sphere_scaled(rr, S.lightSpread[j]);
-                            toL.x -= ld[0]; toL.y -= ld[1]; toL.z -= ld[2];
+                            const float4 ld = light_dir_spread(j);
+                            toL = sphere_scaled(rr, ld.w);
+                            toL.x -= ld.x; toL.y -= ld.y; toL.z -= ld.z;
                             const float inv = 1.f / sqrt_rn(dot3(toL, toL));
                             toL.x *= inv; toL.y *= inv; toL.z *= inv;
                             lmax = RT_INF;
                         } else {
-                            const V3 rp = sphere_scaled(rr, S.lightRadius[j]);
-                            const float *lp = S.lightPos + 4 * j;
-                            toL.x = rp.x + lp[0] - where.x;
-                            toL.y = rp.y + lp[1] - where.y;
-                            toL.z = rp.z + lp[2] - where.z;
+                            const float4 lp = light_pos_radius(j);
+                            const V3 rp = sphere_scaled(rr, lp.w);
+                            toL.x = rp.x + lp.x - where.x;
+                            toL.y = rp.y + lp.y - where.y;
+                            toL.z = rp.z + lp.z - where.z;
                             lmax = sqrt_rn(dot3(toL, toL));
                             const float inv = 1.f / lmax;
                             toL.x *= inv; toL.y *= inv; toL.z *= inv;
@@ -509,13 +551,13 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                     }
                 } else if (pc == PC_LIGHT_ACCUM) { // :628-636
                     const float mag = __builtin_fabsf(ndl);
-                    const float x = lmax / S.lightHalfAtt[j];
+                    const float4 lc = light_col_half(j);
+                    const float x = lmax / lc.w;
                     const float e = mag * half_falloff(x);
-                    const float *lc = S.lightCol + 4 * j;
                     if ((0.f <= ndl) == front) { // face[1] collects the lights in front of the normal, face[0] the others (:632-635)
-                        face.x += (1.f - face.x) * atten.x * e * lc[0];
-                        face.y += (1.f - face.y) * atten.y * e * lc[1];
-                        face.z += (1.f - face.z) * atten.z * e * lc[2];
+                        face.x += (1.f - face.x) * atten.x * e * lc.x;
+                        face.y += (1.f - face.y) * atten.y * e * lc.y;
+                        face.z += (1.f - face.z) * atten.z * e * lc.z;
                     }
                     ++j;
                     pc = PC_LIGHT_SETUP;
@@ -546,6 +588,10 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 }
             }
 
+#ifdef RT_DIAG_LOGIC
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dg2 = diag_stamp();
+#endif
             // Leaving with a request and no look-ahead outstanding: start the next ring entry's grid walk as well.
             if (!finished && laState == 0u && W.lookAhead) {
                 const int nx = (head + 1) % RT_RING;
@@ -580,8 +626,10 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             }
         }
         // every lane of the wave arrives here: one atomic per wave and queue slice for the requests of the next round
-        const uint32_t slot = shard * W.shardCap + wave_append(&countOut[shard], emit);
-        const uint32_t slotLa = (RT_WF_SHARDS + shard) * W.shardCap + wave_append(&countOut[RT_WF_SHARDS + shard], emitLa);
+        uint32_t slot, slotLa;
+        wave_append2(&countOut[shard], emit, &countOut[RT_WF_SHARDS + shard], emitLa, slot, slotLa);
+        slot += shard * W.shardCap;
+        slotLa += (RT_WF_SHARDS + shard) * W.shardCap;
         if (emit) {
             W.reqO[outq][slot] = pack4(ro, rtmin);
             W.reqD[outq][slot] = pack4(rd, rtmax);
@@ -593,6 +641,17 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             W.reqX[outq][slotLa] = make_uint2(laexcl, a);
             W.laSlot[a] = slotLa;
         }
+#ifdef RT_DIAG_LOGIC
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (round < 2u) { // cycle anatomy per round: initial loads | state machine | stores and appends | chunks
+            const unsigned long long dg3 = diag_stamp();
+            const unsigned long long l1 = __shfl((long long)dg1, __ffsll((long long)__ballot(live)) - 1, 64), l2 = __shfl((long long)dg2, __ffsll((long long)__ballot(live)) - 1, 64);
+            if (lane == 0) {
+                atomicAdd(&S.stats[round * 4 + 0], l1 - dg0); atomicAdd(&S.stats[round * 4 + 1], l2 - l1);
+                atomicAdd(&S.stats[round * 4 + 2], dg3 - l2); atomicAdd(&S.stats[round * 4 + 3], 1ull);
+            }
+        }
+#endif
     }
 }
 
@@ -1193,22 +1252,46 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 keys[lane] = ~0ull;
                 if (lane == 0) moreCount[wave] = 0u;
                 __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
+#ifdef RT_WF_TEST_AHEAD
+                // the block words of the NEXT 64 items are requested before this round's records: {owner | order << 6 | bit << 10}, words
+                uint32_t nextWho = 0, nextLo = 0, nextHi = 0, nextRank = 0;
+                auto look_ahead = [&](uint32_t c) {
+                    if (c < items) {
+                        const uint32_t owner = owners[c];
+                        const uint32_t j = c - __shfl(myBase, owner, 64);
+                        const uint32_t pc = cellList[j][(wave << 6) + owner];
+                        const uint32_t *gb = reinterpret_cast<const uint32_t *>(blockTable + (size_t)((pc & 0xFCFCFCu) * 3u));
+                        nextLo = gb[0]; nextHi = gb[1]; nextRank = gb[2];
+                        nextWho = owner | (j << 6) | (((pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u)) << 10);
+                    }
+                };
+                look_ahead(lane);
+#endif
                 for (uint32_t c0 = 0; c0 < items; c0 += 64) {
                     const uint32_t c = c0 + lane;
                     const bool has = c < items;
+#ifdef RT_WF_TEST_AHEAD
+                    const uint32_t owner = nextWho & 63u, j = (nextWho >> 6) & 15u, bit = nextWho >> 10;
+                    const uint32_t lo32 = nextLo, hi32 = nextHi, rank = nextRank;
+                    nextWho = 0u;
+                    if (c0 + 64 < items) look_ahead(c + 64); // (wave-uniform condition: the shuffle inside is executed by all lanes)
+#else
                     const uint32_t owner = has ? owners[c] : 0u;
                     const uint32_t ownerBase = __shfl(myBase, owner, 64);
+#endif
                     const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
                     const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
                     const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64);
                     const uint32_t pexcl = __shfl(excluded, owner, 64);
                     if (has) {
+#ifndef RT_WF_TEST_AHEAD
                         const uint32_t j = c - ownerBase;
                         const uint32_t pc = cellList[j][(wave << 6) + owner];
                         // dense cell id = rank of the block + occupied cells below this one in the block
                         const uint32_t *gb = reinterpret_cast<const uint32_t *>(blockTable + (size_t)((pc & 0xFCFCFCu) * 3u));
                         const uint32_t lo32 = gb[0], hi32 = gb[1], rank = gb[2];
                         const uint32_t bit = (pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u);
+#endif
                         const unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;
                         const uint32_t dense = rank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
                         const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)dense;
