@@ -380,6 +380,11 @@ int build_grid(rtHipScene *sc, const rtHipSceneDesc *d)
     for (int w = 0; w < 3; ++w)
         for (int i = 0; i <= RT_GRID_DIV; ++i) planes[w * (RT_GRID_DIV + 1) + i] = d->boxMin[i].s[w];
     if (sc->upload(planes.data(), planes.size(), &D.boxMin, "boxMin")) return -1;
+    D.planesTame = 1u;
+    for (float pl : planes) {
+        const float m = std::fabs(pl);
+        if (!(m == 0.f || (m >= 0x1p-60f && m <= 0x1p39f))) D.planesTame = 0u;
+    }
     const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
     if (!d->gridStart) return fail("null scenePixelTriangleListStart");
     const uint64_t listSize = d->gridStart[cells];
@@ -534,6 +539,8 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     // rounds with at least this many rays are cut at region boundaries and traced region by region (rt_wavefront.hip, wf_setup_kernel)
     uint32_t regionRays = 0xffffffffu; // off by default: measured slower than length order once a cell visit is one fabric request
     if (const char *b = getenv("RT_WF_REGION_RAYS")) regionRays = (uint32_t)strtoul(b, nullptr, 10);
+    uint32_t fastQuotient = 1u;
+    if (const char *b = getenv("RT_WF_FAST_QUOTIENT")) fastQuotient = (b[0] != '0') ? 1u : 0u;
     uint32_t spinLimit = 16384u; // a ray makes at most 766 cell visits = 96 walk phases; RT_WF_SPIN_LIMIT lowers the guard to test its error path
     if (const char *b = getenv("RT_WF_SPIN_LIMIT")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) spinLimit = (uint32_t)v; }
     uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
@@ -587,11 +594,13 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         memset(G.hostStatus, 0, sizeof(uint32_t) * RT_WF_STATUS_WORDS);
         HIP_OK(hipHostGetDevicePointer((void **)&Wf.hostStatus, G.hostStatus, 0));
         Wf.spinLimit = spinLimit;
+        Wf.fastQuotient = fastQuotient;
         // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
         G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // setup / scatter: two generations of 8 resident workgroups per CU
         G.traceBlocks = (uint32_t)(ecap / 256); // trace: one workgroup per 256 sorted entries, dispatched in order; surplus groups exit at once
+        // (a whole number of waves per queue slice: wf_logic_kernel keeps a wave in one slice)
         G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
-        if (G.logicBlocks == 0) G.logicBlocks = 1;
+        G.logicBlocks = std::max<uint32_t>(RT_WF_SHARDS / 4, (G.logicBlocks + RT_WF_SHARDS / 4 - 1) / (RT_WF_SHARDS / 4) * (RT_WF_SHARDS / 4));
     }
     HIP_OK(hipStreamSynchronize(sc->stream));
     if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');

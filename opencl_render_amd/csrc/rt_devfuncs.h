@@ -282,10 +282,10 @@ __device__ __forceinline__ V3 texel_rec(const RtDevScene &S, const Shared &sh, c
 // ---- shading normal (raytrace_opencl.c:195-263) -----------------------------------------------------------------
 template <bool COUNT>
 __device__ V3 shading_normal(const RtDevScene &S, const Shared &sh, V3 where, V3 ray_o, V3 ray_d, uint32_t tri, float l1, float l2,
-                             const float *shade, int m, Counters &cn, const MatRec *mat = nullptr)
+                             const float *shade, int m, Counters &cn, const MatRec *mat = nullptr, const float4 *firstVertex = nullptr)
 {
     const float4 *rec = reinterpret_cast<const float4 *>(S.triRec) + 4 * (size_t)tri;
-    const float4 r0 = rec[0];
+    const float4 r0 = firstVertex ? *firstVertex : rec[0];
     const V3 a = mk(r0.x, r0.y, r0.z);
     const V3 b = ld3(shade + 0), c = ld3(shade + 3);
     const V3 na = ld3(shade + 6), nb = ld3(shade + 9), nc = ld3(shade + 12);

@@ -62,6 +62,7 @@ struct RtDevScene {
     //                     or more candidates has its exact count in the `count` word of its first FURTHER record.  Pair
     //                     indices therefore stay below 2^28 (build_grid refuses larger scenes: 17 GB of records).
     const uint32_t *gridBlockSparse;
+    uint32_t planesTame;     // every grid plane is 0 or has 2^-60 <= |p| <= 2^39 (see wf_trace_kernel, tame_quotient)
     uint32_t cellCount; // non-empty cells
     const float *pairRec;
     // materials
@@ -128,6 +129,7 @@ struct RtWavefront {
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
     uint32_t samplesInBatch;
     uint32_t lookAhead;      // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
+    uint32_t fastQuotient;   // 1: waves whose rays all have tame exponents skip the scaling / fix-up instructions of the quotients (RT_WF_FAST_QUOTIENT=0 turns it off)
     uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (RT_WF_SPIN_LIMIT, default 16384)
     uint32_t *hostStatus;    // pinned HOST words mapped into the device (RT_WF_STATUS_*): written by kernels, read by the host after a sync
     uint32_t *roundLog;      // [RT_WF_ROUND_LOG] entries (all segments) the trace kernel of round r found, for sizing later frames' launches

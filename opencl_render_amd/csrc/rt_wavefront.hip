@@ -171,6 +171,27 @@ __device__ __forceinline__ uint32_t resolve_hit(const RtDevScene &S, unsigned lo
     return __float_as_uint(r0.w);
 }
 
+// Exponent ranges in which the division (plane - o) / d needs neither operand scaling nor a fix-up (wf_trace_kernel's walk): a
+// plane or origin coordinate is 0 or 2^-60 <= |x| <= 2^39, so n = plane - o is 0 or 2^-84 <= |n| <= 2^40; 2^-40 <= |d| <= 2^40.
+// Then exponent(n) - exponent(d) < 96, neither d, 1/d nor n/d is subnormal, and n is not tiny (the conditions of v_div_scale_f32),
+// and v_div_fixup_f32 returns the quotient it is given (the sign of a zero quotient does not matter: these values are only compared).
+__device__ __forceinline__ bool tame_origin(float x)
+{
+    const float m = __builtin_fabsf(x);
+    return (m == 0.f) | ((m >= 0x1p-60f) & (m <= 0x1p39f));
+}
+__device__ __forceinline__ bool tame_direction(float x)
+{
+    const float m = __builtin_fabsf(x);
+    return (m >= 0x1p-40f) & (m <= 0x1p40f);
+}
+// r1 of the compiler's division sequence: v_rcp_f32, then fma(fma(-d, r0, 1), r0, r0)
+__device__ __forceinline__ float refined_rcp(float dd)
+{
+    const float r0 = __builtin_amdgcn_rcpf(dd);
+    return __builtin_fmaf(__builtin_fmaf(-dd, r0, 1.f), r0, r0);
+}
+
 // Order of the hits of one ray inside a test phase: earlier recorded cell, then smaller t, then earlier candidate.
 __device__ __forceinline__ unsigned long long hit_key(uint32_t cellOrder, float t, uint32_t pair)
 {
@@ -279,8 +300,32 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 #ifndef RT_WF_LOGIC_WAVES
 #define RT_WF_LOGIC_WAVES 3
 #endif
+#ifndef RT_WF_LOGIC_WAVES_FIRST
+#define RT_WF_LOGIC_WAVES_FIRST 2
+#endif
 #define RT_WF_LIGHTS_LDS 64
-__global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+#ifdef RT_DIAG_LOGIC // diagnostic build: where a wave is at which time, round RT_DIAG_LOGIC (no waits added; scripts/diag_logic.py)
+#define DG(i) dg[i] = diag_stamp()
+#else
+#define DG(i)
+#endif
+// What shading a hit reads of its triangle, fetched in one batch: the 24-float shading row (rt_device.h, triShade) and the
+// first vertex (triRec[0]).
+struct TriRow { float v[24]; float4 a; uint32_t tri; };
+__device__ __forceinline__ void load_tri_row(const RtDevScene &S, uint32_t tri, TriRow &row)
+{
+    const float4 *sp = reinterpret_cast<const float4 *>(S.triShade + 24 * (size_t)tri);
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
+    row.a = reinterpret_cast<const float4 *>(S.triRec)[4 * (size_t)tri];
+    row.v[0] = s0.x; row.v[1] = s0.y; row.v[2] = s0.z; row.v[3] = s0.w; row.v[4] = s1.x; row.v[5] = s1.y; row.v[6] = s1.z; row.v[7] = s1.w;
+    row.v[8] = s2.x; row.v[9] = s2.y; row.v[10] = s2.z; row.v[11] = s2.w; row.v[12] = s3.x; row.v[13] = s3.y; row.v[14] = s3.z; row.v[15] = s3.w;
+    row.v[16] = s4.x; row.v[17] = s4.y; row.v[18] = s4.z; row.v[19] = s4.w; row.v[20] = s5.x; row.v[21] = s5.y; row.v[22] = s5.z; row.v[23] = s5.w;
+    row.tri = tri;
+}
+
+// FIRST = round 0: every entry is a primary hit (stage, ring positions and the colour so far are known), a path's id is its queue index.
+template <bool FIRST>
+__global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
 {
     __shared__ Shared sh; // only the texel/255 table is used here
     // the first RT_WF_LIGHTS_LDS lights, one LDS read away instead of a chain of small global loads per light and state
@@ -322,24 +367,18 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
     const bool multiLight = S.lightCount > 1u;
 
     // main requests only (slices [0, RT_WF_SHARDS)): one per waiting path; look-ahead answers are picked up by index.
-    // Slices are sized for the worst case (every pixel a path) and filled evenly (round-robin shards), so the loop runs
-    // chunk-major up to the longest slice instead of over the whole capacity.
-    uint32_t longest = 0;
-#pragma unroll
-    for (int i = 0; i < RT_WF_SHARDS / 64; ++i) longest = max(longest, countIn[i * 64 + lane]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
-    const uint32_t usedChunks = (longest + 63u) >> 6;
-    for (uint32_t chunk = waveId; chunk < RT_WF_SHARDS * usedChunks; chunk += waves) {
-        const uint32_t shard = chunk % RT_WF_SHARDS, localChunk = chunk / RT_WF_SHARDS;
-        const uint32_t total = countIn[shard];
+    // The grid is a whole number of waves per slice (rtw_launch_logic), so a wave stays in ONE slice and needs its length only:
+    // slice = wave id % RT_WF_SHARDS, chunks of 64 entries dealt to the slice's waves in turn.
+    const uint32_t shard = waveId % RT_WF_SHARDS;
+    const uint32_t total = countIn[shard];
+    for (uint32_t localChunk = waveId / RT_WF_SHARDS; localChunk * 64 < total; localChunk += waves / RT_WF_SHARDS) {
         const uint32_t local = localChunk * 64 + lane;
-        if (localChunk * 64 >= total) continue; // wave-uniform
         const uint32_t q = shard * W.shardCap + local;
         const bool live = local < total;
 #ifdef RT_DIAG_LOGIC
-        const unsigned long long dg0 = diag_stamp();
-        unsigned long long dg1 = dg0, dg2 = dg0;
+        unsigned long long dg[10];
+        dg[0] = diag_stamp();
+        for (int i = 1; i < 10; ++i) dg[i] = 0;
 #endif
         bool emit = false, emitLa = false;
         V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), lo3 = mk(0, 0, 0), ld3v = mk(0, 0, 0);
@@ -347,19 +386,37 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         uint32_t rexcl = RT_NONE, laexcl = RT_NONE, a = 0;
 
         if (live) {
-            a = (round == 0u) ? q : W.reqX[in][q].y; // (a path is born at its own round-0 queue index: one dependent load fewer)
-            // round 0 consumes the primary hits (res); later rounds the keys the trace kernel left (hitKey), resolved below
+            // Round 0 issues its loads in as few dependent batches as the data allows -- a wave runs one chunk and has one or two
+            // neighbours on its SIMD, so the chunk lasts as long as its chain of memory round trips (measured: ~8 of them at
+            // 2-4 us each before the first shading instruction when every load sat next to its use).  Batch one: the primary hit,
+            // the path's state and the camera ray; batch two: the hit triangle's shading row.  That costs registers: the round-0
+            // instantiation runs at 2 waves per SIMD (213 VGPRs, nothing spilled: 114 -> 100 us), later rounds, whose paths are
+            // in different stages, keep their loads next to the uses and 3 waves (batching them too measured 100 -> 120 us).
             uint32_t res_tri = RT_NONE;
             float res_t = 0.f, res_l1 = 0.f, res_l2 = 0.f;
             unsigned long long key = ~0ull;
-            if (round == 0u) {
+            float4 qo = make_float4(0.f, 0.f, 0.f, 0.f), qd = qo;
+            if (FIRST) {
+                a = q; // (a path is born at its own round-0 queue index)
                 const uint4 r = W.res[q];
                 res_tri = r.x; res_t = __uint_as_float(r.y); res_l1 = __uint_as_float(r.z); res_l2 = __uint_as_float(r.w);
-            } else key = W.hitKey[q];
-
+            } else {
+                const uint2 rx = W.reqX[in][q];
+                key = W.hitKey[q];
+                a = rx.y;
+            }
+            float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
             uint64_t rng = W.rng[a];
             const uint4 meta = W.meta[a];
-            V3 out = xyz(W.outc[a]);
+            V3 out = mk(0.f, 0.f, 0.f); // (round 0: nothing collected yet)
+            float4 c0 = qo, c1 = qo, c2 = qo;
+            unsigned long long laKey = ~0ull;
+            TriRow row;
+            row.tri = RT_NONE;
+            if (FIRST) {
+                c0 = ringA[0]; c1 = ringA[1]; c2 = ringA[2]; // slot 0 = the camera ray
+                load_tri_row(S, res_tri, row);
+            } else out = xyz(W.outc[a]);
             uint32_t hit_tri = meta.w;
             int head = (int)(meta.z & 15u), tail = (int)((meta.z >> 4) & 15u);
             const uint32_t stage = (meta.z >> 8) & 1u;
@@ -367,8 +424,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             uint32_t laState = (meta.z >> 10) & 3u; // 0 none, 1 requested last round (answer at res[laSlot]), 2 answer kept in laRes
             int laIndex = (int)((meta.z >> 12) & 15u);
             uint32_t j = meta.z >> 16;
-            float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
-            unsigned long long laKey = ~0ull;
+            DG(1);
             bool laFetched = false;
             if (laState == 1u) { laKey = W.hitKey[W.laSlot[a]]; laState = 2u; laFetched = true; }
             else if (laState == 2u) laKey = W.laKey[a];
@@ -388,117 +444,125 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
 
             enum { PC_RAY_RESULT, PC_SHADOW_RESULT, PC_LIGHT_SETUP, PC_LIGHT_ACCUM, PC_SHADE_END, PC_NEXT_RAY, PC_EXIT };
             int pc = PC_RAY_RESULT;
-            if (stage == WS_SHADOW) {
+            if (!FIRST && stage == WS_SHADOW) {
                 const float4 sp = W.shP[a], sf = W.shFace[a];
                 P = xyz(sp); ndl = sp.w; face = xyz(sf); front = (sf.w != 0.f);
                 if (attStored) atten = xyz(W.shAtt[a]);
                 // the request that was answered still holds the hit point and the direction to the light
-                const float4 qo = W.reqO[in][q], qd = W.reqD[in][q];
+                qo = W.reqO[in][q]; qd = W.reqD[in][q];
                 where = xyz(qo); lmin = qo.w; toL = xyz(qd); lmax = qd.w;
                 if (multiLight) { n = xyz(W.shN[a]); rngL = W.rngL[a]; }
                 res_tri = resolve_hit(S, key, where, toL, lmin, lmax, hit_tri, res_t, res_l1, res_l2);
                 pc = PC_SHADOW_RESULT;
             } else {
-                const float4 c0 = ringA[head * 3 + 0], c1 = ringA[head * 3 + 1], c2 = ringA[head * 3 + 2];
+                if (!FIRST) { c0 = ringA[head * 3 + 0]; c1 = ringA[head * 3 + 1]; c2 = ringA[head * 3 + 2]; }
                 cur_o = xyz(c0); cur_tmin = c0.w; cur_d = xyz(c1); cur_excl = __float_as_uint(c1.w); cur_w = xyz(c2);
                 cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
                 cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
-                if (round != 0u) res_tri = resolve_hit(S, key, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
+                if (!FIRST) res_tri = resolve_hit(S, key, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
             }
+            DG(2);
             bool finished = false, shadedNow = false, rngDirty = false, outDirty = false;
             uint32_t emitStage = WS_RAY;
-#ifdef RT_DIAG_LOGIC
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dg1 = diag_stamp();
-#endif
 
+            // A spawned ray goes to the ring in HBM; the first one of this invocation also stays in registers, because it is the
+            // ray the look-ahead below will ask for when the ring was empty (reading it back cost a round trip behind the stores).
+            // Round 0 only: later rounds have no registers to spare.
+            int firstSpawnSlot = -1;
+            float4 firstSpawn0 = make_float4(0.f, 0.f, 0.f, 0.f), firstSpawn1 = firstSpawn0;
+            uint32_t firstSpawnFlags = 0u;
+            auto spawn = [&](float4 e0, float4 e1, float4 e2) {
+                ringA[tail * 3 + 0] = e0; ringA[tail * 3 + 1] = e1; ringA[tail * 3 + 2] = e2;
+                if (FIRST && firstSpawnSlot < 0) { firstSpawnSlot = tail; firstSpawn0 = e0; firstSpawn1 = e1; firstSpawnFlags = __float_as_uint(e2.w); }
+                tail = (tail + 1) % RT_RING;
+            };
+            // SHADE_BEGIN (:532-561) and the hit's spawns, on the triangle's shading row
+            auto shade_begin = [&](const float *shade, const float4 *firstVertex) {
+                hit_tri = res_tri;
+                const float hit_t = res_t, hit_l1 = res_l1, hit_l2 = res_l2;
+                const int m = __float_as_int(shade[21]);
+                if (m != 12345678) DG(3);
+                const float *uv = shade + 15;
+                where = along(cur_o, hit_t, cur_d);
+                // the material's whole record in one burst (rt_device.h, matRec): the channel look-ups below are then no chain
+                // of dependent loads, and one-texel channels need no further load at all
+                MatRec mat;
+                mat.desc[0] = mat.desc[1] = mat.desc[2] = mat.desc[3] = mat.desc[4] = 0u; mat.m = m;
+                if (0 <= m) mat = load_mat(S, m);
+                n = shading_normal<false>(S, sh, where, cur_o, cur_d, hit_tri, hit_l1, hit_l2, shade, m, cn, &mat, firstVertex);
+                if (n.x != 12345.f) DG(4);
+                V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
+                if (0 <= m) {
+                    uint32_t raw;
+                    if (mat.desc[CH_COLOR]) tex = texel_rec<false>(S, sh, mat, CH_COLOR, uv, hit_l1, hit_l2, raw, cn);
+                    if (mat.desc[CH_TRANSPARENCY]) transp = texel_rec<false>(S, sh, mat, CH_TRANSPARENCY, uv, hit_l1, hit_l2, raw, cn);
+                    if (mat.desc[CH_REFLECTION]) refl = texel_rec<false>(S, sh, mat, CH_REFLECTION, uv, hit_l1, hit_l2, raw, cn);
+                    if (mat.desc[CH_LUMINANCE]) lum = texel_rec<false>(S, sh, mat, CH_LUMINANCE, uv, hit_l1, hit_l2, raw, cn);
+                }
+                // :642-644 now (the light loop does not touch `out`), then the light-independent factors of :649-651
+                out.x += (1.f - out.x) * lum.x * cur_w.x;
+                out.y += (1.f - out.y) * lum.y * cur_w.y;
+                out.z += (1.f - out.z) * lum.z * cur_w.z;
+                outDirty = true;
+                front = (dot3(n, cur_d) <= 0.f);
+                P.x = (1.f - out.x) * cur_w.x * (1.f - transp.x) * tex.x;
+                P.y = (1.f - out.y) * cur_w.y * (1.f - transp.y) * tex.y;
+                P.z = (1.f - out.z) * cur_w.z * (1.f - transp.z) * tex.z;
+                face = mk(0.1f, 0.1f, 0.1f); // :540
+                // The light loop (:563-637) draws one GetSpherePoint per light of a sampled type (:573,:595).  Make those
+                // draws now: keep light 0's, remember where light 1's start, and leave the generator behind them all.
+                rngL = rng;
+                for (uint32_t k = 0; k < S.lightCount; ++k) {
+                    const int type = light_type(k);
+                    if (type >= 1 && type <= 9) {
+                        const SphereRaw rr = sphere_raw(rng);
+                        if (k == 0) raw0 = rr;
+                    }
+                    if (k == 0) rngL = rng;
+                }
+                rngDirty = true;
+                // the hit's spawns (:656-722), ahead of its light loop: nothing below depends on the face lights
+                if (cur_bounces > 0) {
+                    const int frontI = front ? 1 : 0;
+                    const float total_rt = RT_MAX2(RT_MAX2(refl.x + transp.x, refl.y + transp.y), refl.z + transp.z);
+                    const float dif = (total_rt < 1.f) ? 1.f - total_rt : 0.f;
+                    bool open = true;
+                    V3 w = mk(cur_w.x * tex.x * dif, cur_w.y * tex.y * dif, cur_w.z * tex.z * dif);
+                    if (3.f / 256.f <= w.x + w.y + w.z) { // diffuse bounce (:664-683)
+                        V3 nd = sphere_scaled(sphere_raw(rng), 1.f);
+                        if (frontI != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
+                        spawn(pack4(where, 0.f), pack4(nd, __uint_as_float(hit_tri)), pack4(w, __uint_as_float(0u)));
+                        if ((tail + 1) % RT_RING == head) open = false;
+                    }
+                    if (open) { // mirror (:686-705)
+                        w = mk(cur_w.x * tex.x * refl.x, cur_w.y * tex.y * refl.y, cur_w.z * tex.z * refl.z);
+                        if (3.f / 256.f <= w.x + w.y + w.z) {
+                            const float two = -2.f * dot3(n, cur_d);
+                            const V3 md = mk(cur_d.x + two * n.x, cur_d.y + two * n.y, cur_d.z + two * n.z);
+                            spawn(pack4(where, 0.f), pack4(md, __uint_as_float(hit_tri)), pack4(w, __uint_as_float((uint32_t)(cur_bounces - 1) << 1)));
+                            if ((tail + 1) % RT_RING == head) open = false;
+                        }
+                    }
+                    if (open) { // see-through continuation (:707-722)
+                        w = mk(cur_w.x * tex.x * transp.x, cur_w.y * tex.y * transp.y, cur_w.z * tex.z * transp.z);
+                        if (3.f / 256.f <= w.x + w.y + w.z) {
+                            spawn(pack4(cur_o, hit_t), pack4(cur_d, __uint_as_float(hit_tri)),
+                                  pack4(w, __uint_as_float(((uint32_t)(cur_bounces - 1) << 1) | (uint32_t)cur_fromCamera)));
+                        }
+                    }
+                }
+                DG(5);
+                j = 0;
+                shadedNow = true;
+                pc = PC_LIGHT_SETUP;
+            };
+            if (FIRST) { // the camera ray's hit: its row was requested with the path's state
+                if (res_tri != RT_NONE) shade_begin(row.v, &row.a); else pc = PC_NEXT_RAY;
+            }
             while (pc != PC_EXIT) {
                 if (pc == PC_RAY_RESULT) {
                     if (res_tri == RT_NONE) { pc = PC_NEXT_RAY; continue; }
-                    // SHADE_BEGIN (:532-561)
-                    hit_tri = res_tri;
-                    const float hit_t = res_t, hit_l1 = res_l1, hit_l2 = res_l2;
-                    const float *shade = S.triShade + 24 * (size_t)hit_tri;
-                    const int m = __float_as_int(shade[21]);
-                    const float *uv = shade + 15;
-                    where = along(cur_o, hit_t, cur_d);
-                    // the material's whole record in one burst (rt_device.h, matRec): the channel look-ups below are then no chain
-                    // of dependent loads, and one-texel channels need no further load at all
-                    MatRec mat;
-                    mat.desc[0] = mat.desc[1] = mat.desc[2] = mat.desc[3] = mat.desc[4] = 0u; mat.m = m;
-                    if (0 <= m) mat = load_mat(S, m);
-                    n = shading_normal<false>(S, sh, where, cur_o, cur_d, hit_tri, hit_l1, hit_l2, shade, m, cn, &mat);
-                    V3 tex = mk(0, 0, 0), transp = mk(0, 0, 0), refl = mk(0, 0, 0), lum = mk(0, 0, 0);
-                    if (0 <= m) {
-                        uint32_t raw;
-                        if (mat.desc[CH_COLOR]) tex = texel_rec<false>(S, sh, mat, CH_COLOR, uv, hit_l1, hit_l2, raw, cn);
-                        if (mat.desc[CH_TRANSPARENCY]) transp = texel_rec<false>(S, sh, mat, CH_TRANSPARENCY, uv, hit_l1, hit_l2, raw, cn);
-                        if (mat.desc[CH_REFLECTION]) refl = texel_rec<false>(S, sh, mat, CH_REFLECTION, uv, hit_l1, hit_l2, raw, cn);
-                        if (mat.desc[CH_LUMINANCE]) lum = texel_rec<false>(S, sh, mat, CH_LUMINANCE, uv, hit_l1, hit_l2, raw, cn);
-                    }
-                    // :642-644 now (the light loop does not touch `out`), then the light-independent factors of :649-651
-                    out.x += (1.f - out.x) * lum.x * cur_w.x;
-                    out.y += (1.f - out.y) * lum.y * cur_w.y;
-                    out.z += (1.f - out.z) * lum.z * cur_w.z;
-                    outDirty = true;
-                    front = (dot3(n, cur_d) <= 0.f);
-                    P.x = (1.f - out.x) * cur_w.x * (1.f - transp.x) * tex.x;
-                    P.y = (1.f - out.y) * cur_w.y * (1.f - transp.y) * tex.y;
-                    P.z = (1.f - out.z) * cur_w.z * (1.f - transp.z) * tex.z;
-                    face = mk(0.1f, 0.1f, 0.1f); // :540
-                    // The light loop (:563-637) draws one GetSpherePoint per light of a sampled type (:573,:595).  Make those
-                    // draws now: keep light 0's, remember where light 1's start, and leave the generator behind them all.
-                    rngL = rng;
-                    for (uint32_t k = 0; k < S.lightCount; ++k) {
-                        const int type = light_type(k);
-                        if (type >= 1 && type <= 9) {
-                            const SphereRaw rr = sphere_raw(rng);
-                            if (k == 0) raw0 = rr;
-                        }
-                        if (k == 0) rngL = rng;
-                    }
-                    rngDirty = true;
-                    // the hit's spawns (:656-722), ahead of its light loop: nothing below depends on the face lights
-                    if (cur_bounces > 0) {
-                        const int frontI = front ? 1 : 0;
-                        const float total_rt = RT_MAX2(RT_MAX2(refl.x + transp.x, refl.y + transp.y), refl.z + transp.z);
-                        const float dif = (total_rt < 1.f) ? 1.f - total_rt : 0.f;
-                        bool open = true;
-                        V3 w = mk(cur_w.x * tex.x * dif, cur_w.y * tex.y * dif, cur_w.z * tex.z * dif);
-                        if (3.f / 256.f <= w.x + w.y + w.z) { // diffuse bounce (:664-683)
-                            V3 nd = sphere_scaled(sphere_raw(rng), 1.f);
-                            if (frontI != ((0 <= dot3(nd, n)) ? 1 : 0)) { nd.x = -nd.x; nd.y = -nd.y; nd.z = -nd.z; }
-                            ringA[tail * 3 + 0] = pack4(where, 0.f);
-                            ringA[tail * 3 + 1] = pack4(nd, __uint_as_float(hit_tri));
-                            ringA[tail * 3 + 2] = pack4(w, __uint_as_float(0u));
-                            tail = (tail + 1) % RT_RING;
-                            if ((tail + 1) % RT_RING == head) open = false;
-                        }
-                        if (open) { // mirror (:686-705)
-                            w = mk(cur_w.x * tex.x * refl.x, cur_w.y * tex.y * refl.y, cur_w.z * tex.z * refl.z);
-                            if (3.f / 256.f <= w.x + w.y + w.z) {
-                                const float two = -2.f * dot3(n, cur_d);
-                                const V3 md = mk(cur_d.x + two * n.x, cur_d.y + two * n.y, cur_d.z + two * n.z);
-                                ringA[tail * 3 + 0] = pack4(where, 0.f);
-                                ringA[tail * 3 + 1] = pack4(md, __uint_as_float(hit_tri));
-                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float((uint32_t)(cur_bounces - 1) << 1));
-                                tail = (tail + 1) % RT_RING;
-                                if ((tail + 1) % RT_RING == head) open = false;
-                            }
-                        }
-                        if (open) { // see-through continuation (:707-722)
-                            w = mk(cur_w.x * tex.x * transp.x, cur_w.y * tex.y * transp.y, cur_w.z * tex.z * transp.z);
-                            if (3.f / 256.f <= w.x + w.y + w.z) {
-                                ringA[tail * 3 + 0] = pack4(cur_o, hit_t);
-                                ringA[tail * 3 + 1] = pack4(cur_d, __uint_as_float(hit_tri));
-                                ringA[tail * 3 + 2] = pack4(w, __uint_as_float(((uint32_t)(cur_bounces - 1) << 1) | (uint32_t)cur_fromCamera));
-                                tail = (tail + 1) % RT_RING;
-                            }
-                        }
-                    }
-                    j = 0;
-                    shadedNow = true;
-                    pc = PC_LIGHT_SETUP;
+                    shade_begin(S.triShade + 24 * (size_t)res_tri, nullptr); // (read where it is used: registers, see above)
                 } else if (pc == PC_LIGHT_SETUP) { // :563-607
                     if (j >= S.lightCount) { pc = PC_SHADE_END; continue; }
                     toL = mk(0.f, 0.f, 0.f); atten = mk(1.f, 1.f, 1.f); attStored = false;
@@ -588,22 +652,22 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
                 }
             }
 
-#ifdef RT_DIAG_LOGIC
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dg2 = diag_stamp();
-#endif
+            DG(6);
             // Leaving with a request and no look-ahead outstanding: start the next ring entry's grid walk as well.
             if (!finished && laState == 0u && W.lookAhead) {
                 const int nx = (head + 1) % RT_RING;
                 if (nx != tail) {
-                    const float4 n0 = ringA[nx * 3 + 0], n1 = ringA[nx * 3 + 1], n2 = ringA[nx * 3 + 2];
-                    if ((__float_as_uint(n2.w) & 1u) == 0u) { // a grid ray (camera-type rays are answered inline)
+                    float4 n0 = firstSpawn0, n1 = firstSpawn1;
+                    uint32_t nflags = firstSpawnFlags;
+                    if (!FIRST || nx != firstSpawnSlot) { n0 = ringA[nx * 3 + 0]; n1 = ringA[nx * 3 + 1]; nflags = __float_as_uint(ringA[nx * 3 + 2].w); }
+                    if ((nflags & 1u) == 0u) { // a grid ray (camera-type rays are answered inline)
                         emitLa = true; lo3 = xyz(n0); latmin = n0.w; ld3v = xyz(n1); laexcl = __float_as_uint(n1.w);
                         laState = 1u; laIndex = nx;
                     }
                 }
             }
 
+            if (laexcl != 12345u) DG(7);
             if (finished) {
                 if (S.sampleCount == 1u) store_single_sample(S, meta.y, out);
                 else W.sampleOut[meta.x] = pack4(out, 0.f);
@@ -630,6 +694,7 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
         wave_append2(&countOut[shard], emit, &countOut[RT_WF_SHARDS + shard], emitLa, slot, slotLa);
         slot += shard * W.shardCap;
         slotLa += (RT_WF_SHARDS + shard) * W.shardCap;
+        if (slot != 0xfffffff0u) DG(8);
         if (emit) {
             W.reqO[outq][slot] = pack4(ro, rtmin);
             W.reqD[outq][slot] = pack4(rd, rtmax);
@@ -642,13 +707,17 @@ __global__ __launch_bounds__(256, RT_WF_LOGIC_WAVES) void wf_logic_kernel(const 
             W.laSlot[a] = slotLa;
         }
 #ifdef RT_DIAG_LOGIC
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (round < 2u) { // cycle anatomy per round: initial loads | state machine | stores and appends | chunks
-            const unsigned long long dg3 = diag_stamp();
-            const unsigned long long l1 = __shfl((long long)dg1, __ffsll((long long)__ballot(live)) - 1, 64), l2 = __shfl((long long)dg2, __ffsll((long long)__ballot(live)) - 1, 64);
+        if (round == RT_DIAG_LOGIC) {
+            dg[9] = diag_stamp();
+            // a stamp taken in a divergent branch belongs to the wave: take the latest any lane saw, and keep the sequence monotone
+            for (int i = 1; i < 10; ++i) {
+                unsigned long long v = dg[i];
+                for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o2 = __shfl_xor((long long)v, off, 64); v = v > o2 ? v : o2; }
+                dg[i] = v > dg[i - 1] ? v : dg[i - 1];
+            }
             if (lane == 0) {
-                atomicAdd(&S.stats[round * 4 + 0], l1 - dg0); atomicAdd(&S.stats[round * 4 + 1], l2 - l1);
-                atomicAdd(&S.stats[round * 4 + 2], dg3 - l2); atomicAdd(&S.stats[round * 4 + 3], 1ull);
+                for (int i = 0; i < 7; ++i) atomicAdd(&S.stats[i], dg[i + 1] - dg[i]);
+                atomicAdd(&S.stats[7], dg[9] - dg[7]);
             }
         }
 #endif
@@ -1114,6 +1183,8 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
         seg = c3.w >> 24;
     }
+    const bool fastWave = S.planesTame && W.fastQuotient && __ballot(active && !(tame_origin(o.x) && tame_origin(o.y) && tame_origin(o.z) &&
+                                                                               tame_direction(d.x) && tame_direction(d.y) && tame_direction(d.z))) == 0ull;
     // per-axis step constants (:387-398): direction of travel is fixed per ray
     const bool px = (0.f <= d.x), py = (0.f <= d.y), pz = (0.f <= d.z);
     const uint32_t stepX = px ? 1u : (uint32_t)-1, stepY = py ? (1u << 8) : (uint32_t)-(1 << 8), stepZ = pz ? (1u << 16) : (uint32_t)-(1 << 16);
@@ -1151,37 +1222,56 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
             dgWalkIters++;
 #endif
             uint32_t logged = 0;
-#pragma unroll
-            for (int u = 0; u < RT_WF_BLIND; ++u) {
-#ifdef RT_DIAG_STAMPS
-                dgSteps += (unsigned long long)__popcll(__ballot(canWalk && !walkEnded));
-#endif
-                if (canWalk && !walkEnded) {
-                    cellList[listed + logged][threadIdx.x] = cell;
-                    ++logged;
-                    // the end cell ends the walk after it has been visited (:380-381)
-                    bool done = (cell == endCell);
-                    if (!done) {
-                        // axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z
-                        const bool sxm = (dx < dy) & (dx < dz);
-                        const bool sym = !sxm & (dy < dz);
-                        const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);
-                        const uint32_t stepSel = sxm ? stepX : (sym ? stepY : stepZ);
-                        // the step would leave the grid (:389,:393,:397): coordinate 255 going up, 0 going down
-                        done = (((cell >> shift) & 255u) == (((int32_t)stepSel > 0) ? 255u : 0u));
-                        if (!done) {
-                            cell += stepSel;
-                            const uint32_t off = sxm ? offX : (sym ? offY : offZ);
-                            const float plane = *reinterpret_cast<const float *>(planeBytes + (((cell >> shift) & 255u) << 2) + off);
-                            const float dd = sxm ? d.x : (sym ? d.y : d.z);
-                            const float oo = sxm ? o.x : (sym ? o.y : o.z);
-                            const float nd = (plane - oo) / dd;
-                            dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;
-                        }
-                    }
-                    walkEnded = done;
+            // The quotient (plane - o) / d is the correctly rounded one, as the compiler expands it: v_div_scale x2, v_rcp, two
+            // refinements of the reciprocal, q0 = n*r, two corrections, v_div_fmas, v_div_fixup.  When the exponents of n and d
+            // are tame (tame_ray below) the scale instructions return their operands, v_div_fmas is a plain fma and the fix-up
+            // returns its input: what is left is q0 = n*r1, e1 = fma(-d,q0,n), q1 = fma(e1,r1,q0), e2 = fma(-d,q1,n),
+            // q2 = fma(e2,r1,q1) with r1 = the refined reciprocal, which depends on the axis only -- the same operations on the
+            // same operands, bit for bit, in 5 issue slots instead of 14 (v_rcp_f32 is quarter rate).  A wave takes this path
+            // when all of its rays are tame; the reciprocals live in registers only while the wave walks.
+#define RT_WALK_STEP(FAST)                                                                                                          \
+                if (canWalk && !walkEnded) {                                                                                        \
+                    cellList[listed + logged][threadIdx.x] = cell;                                                                  \
+                    ++logged;                                                                                                       \
+                    /* the end cell ends the walk after it has been visited (:380-381) */                                           \
+                    bool done = (cell == endCell);                                                                                  \
+                    if (!done) {                                                                                                    \
+                        /* axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z */                 \
+                        const bool sxm = (dx < dy) & (dx < dz);                                                                     \
+                        const bool sym = !sxm & (dy < dz);                                                                          \
+                        const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);                                                         \
+                        const uint32_t stepSel = sxm ? stepX : (sym ? stepY : stepZ);                                               \
+                        /* the step would leave the grid (:389,:393,:397): coordinate 255 going up, 0 going down */                 \
+                        done = (((cell >> shift) & 255u) == (((int32_t)stepSel > 0) ? 255u : 0u));                                  \
+                        if (!done) {                                                                                                \
+                            cell += stepSel;                                                                                        \
+                            const uint32_t off = sxm ? offX : (sym ? offY : offZ);                                                  \
+                            const float plane = *reinterpret_cast<const float *>(planeBytes + (((cell >> shift) & 255u) << 2) + off); \
+                            const float dd = sxm ? d.x : (sym ? d.y : d.z);                                                         \
+                            const float oo = sxm ? o.x : (sym ? o.y : o.z);                                                         \
+                            float nd;                                                                                               \
+                            if (FAST) {                                                                                             \
+                                const float rr = sxm ? rx : (sym ? ry : rz);                                                        \
+                                const float nn = plane - oo;                                                                        \
+                                const float q0 = nn * rr;                                                                           \
+                                const float q1 = __builtin_fmaf(__builtin_fmaf(-dd, q0, nn), rr, q0);                               \
+                                nd = __builtin_fmaf(__builtin_fmaf(-dd, q1, nn), rr, q1);                                           \
+                            } else nd = (plane - oo) / dd;                                                                          \
+                            dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;                                     \
+                        }                                                                                                           \
+                    }                                                                                                               \
+                    walkEnded = done;                                                                                               \
                 }
+            if (fastWave) {
+                const float rx = refined_rcp(d.x), ry = refined_rcp(d.y), rz = refined_rcp(d.z);
+#pragma unroll
+                for (int u = 0; u < RT_WF_BLIND; ++u) { RT_WALK_STEP(true) }
+            } else {
+                const float rx = 0.f, ry = 0.f, rz = 0.f;
+#pragma unroll
+                for (int u = 0; u < RT_WF_BLIND; ++u) { RT_WALK_STEP(false) }
             }
+#undef RT_WALK_STEP
             // look-up: which of the logged cells are occupied?  Keep those, in path order, at the front of the list.  Only the
             // requested words stay in registers across the wait; the logged cells are read back from LDS on both sides of it
             // (what a word is needed for -- "the block differs from the one before" -- is recomputed the same way).
@@ -1252,46 +1342,22 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 keys[lane] = ~0ull;
                 if (lane == 0) moreCount[wave] = 0u;
                 __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
-#ifdef RT_WF_TEST_AHEAD
-                // the block words of the NEXT 64 items are requested before this round's records: {owner | order << 6 | bit << 10}, words
-                uint32_t nextWho = 0, nextLo = 0, nextHi = 0, nextRank = 0;
-                auto look_ahead = [&](uint32_t c) {
-                    if (c < items) {
-                        const uint32_t owner = owners[c];
-                        const uint32_t j = c - __shfl(myBase, owner, 64);
-                        const uint32_t pc = cellList[j][(wave << 6) + owner];
-                        const uint32_t *gb = reinterpret_cast<const uint32_t *>(blockTable + (size_t)((pc & 0xFCFCFCu) * 3u));
-                        nextLo = gb[0]; nextHi = gb[1]; nextRank = gb[2];
-                        nextWho = owner | (j << 6) | (((pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u)) << 10);
-                    }
-                };
-                look_ahead(lane);
-#endif
                 for (uint32_t c0 = 0; c0 < items; c0 += 64) {
                     const uint32_t c = c0 + lane;
                     const bool has = c < items;
-#ifdef RT_WF_TEST_AHEAD
-                    const uint32_t owner = nextWho & 63u, j = (nextWho >> 6) & 15u, bit = nextWho >> 10;
-                    const uint32_t lo32 = nextLo, hi32 = nextHi, rank = nextRank;
-                    nextWho = 0u;
-                    if (c0 + 64 < items) look_ahead(c + 64); // (wave-uniform condition: the shuffle inside is executed by all lanes)
-#else
                     const uint32_t owner = has ? owners[c] : 0u;
                     const uint32_t ownerBase = __shfl(myBase, owner, 64);
-#endif
                     const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
                     const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
                     const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64);
                     const uint32_t pexcl = __shfl(excluded, owner, 64);
                     if (has) {
-#ifndef RT_WF_TEST_AHEAD
                         const uint32_t j = c - ownerBase;
                         const uint32_t pc = cellList[j][(wave << 6) + owner];
                         // dense cell id = rank of the block + occupied cells below this one in the block
                         const uint32_t *gb = reinterpret_cast<const uint32_t *>(blockTable + (size_t)((pc & 0xFCFCFCu) * 3u));
                         const uint32_t lo32 = gb[0], hi32 = gb[1], rank = gb[2];
                         const uint32_t bit = (pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u);
-#endif
                         const unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;
                         const uint32_t dense = rank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
                         const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)dense;
@@ -1432,7 +1498,9 @@ extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefr
 
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(wf_logic_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    if (blocks % (RT_WF_SHARDS / 4) != 0) return hipErrorInvalidValue; // a whole number of waves per queue slice (wf_logic_kernel)
+    if (round == 0u) hipLaunchKernelGGL(wf_logic_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    else hipLaunchKernelGGL(wf_logic_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
     return hipGetLastError();
 }
 
