@@ -372,7 +372,7 @@ int rtHipWritePpm(const char *path, cl_uint width, cl_uint height, const cl_usho
  * are documented at the top of rt_kat.hip.  `table` is only read by RT_KAT_BOX (split planes, 3 x 257 floats, one
  * array per axis).  Returns 0, -1 bad arguments, -2 no such device (there is no CPU stand-in), -3 HIP failure.
  * ---------------------------------------------------------------------------------------------------------- */
-enum { RT_KAT_RANDF = 0, RT_KAT_SPHERE, RT_KAT_PMODF, RT_KAT_TRI, RT_KAT_PLINE, RT_KAT_BOX, RT_KAT_BIND, RT_KAT_POW, RT_KAT_OPS };
+enum { RT_KAT_RANDF = 0, RT_KAT_SPHERE, RT_KAT_PMODF, RT_KAT_TRI, RT_KAT_PLINE, RT_KAT_BOX, RT_KAT_BIND, RT_KAT_POW, RT_KAT_QUOTIENT, RT_KAT_OPS };
 int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint inStride, void *out, cl_uint outStride, const float *table);
 
 #ifdef __cplusplus

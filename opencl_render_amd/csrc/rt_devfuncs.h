@@ -279,6 +279,36 @@ __device__ __forceinline__ V3 texel_rec(const RtDevScene &S, const Shared &sh, c
     return texel<COUNT>(S, sh, S.matStart[at], S.matSize[2 * at], S.matSize[2 * at + 1], uv, l1, l2, raw, cn);
 }
 
+// Exponent ranges in which the division (plane - o) / d needs neither operand scaling nor a fix-up (wf_trace_kernel's walk, rt_wavefront.hip): a
+// plane or origin coordinate is 0 or 2^-60 <= |x| <= 2^39, so n = plane - o is 0 or 2^-84 <= |n| <= 2^40; 2^-40 <= |d| <= 2^40.
+// Then exponent(n) - exponent(d) < 96, neither d, 1/d nor n/d is subnormal, and n is not tiny (the conditions of v_div_scale_f32),
+// and v_div_fixup_f32 returns the quotient it is given (the sign of a zero quotient does not matter: these values are only compared).
+__device__ __forceinline__ bool tame_origin(float x)
+{
+    const float m = __builtin_fabsf(x);
+    return (m == 0.f) | ((m >= 0x1p-60f) & (m <= 0x1p39f));
+}
+__device__ __forceinline__ bool tame_direction(float x)
+{
+    const float m = __builtin_fabsf(x);
+    return (m >= 0x1p-40f) & (m <= 0x1p40f);
+}
+// r1 of the compiler's division sequence: v_rcp_f32, then fma(fma(-d, r0, 1), r0, r0)
+__device__ __forceinline__ float refined_rcp(float dd)
+{
+    const float r0 = __builtin_amdgcn_rcpf(dd);
+    return __builtin_fmaf(__builtin_fmaf(-dd, r0, 1.f), r0, r0);
+}
+
+// The walk's quotient without the scaling and fix-up instructions: only for tame operands (above), where it is the compiler's
+// own sequence minus instructions that do nothing there.  r1 = refined_rcp(d).
+__device__ __forceinline__ float tame_quotient(float n, float d, float r1)
+{
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+
 // ---- shading normal (raytrace_opencl.c:195-263) -----------------------------------------------------------------
 template <bool COUNT>
 __device__ V3 shading_normal(const RtDevScene &S, const Shared &sh, V3 where, V3 ray_o, V3 ray_d, uint32_t tri, float l1, float l2,

@@ -11,6 +11,7 @@
 //   RT_KAT_BOX        p3 (table = split planes, 3 x 257 f32 SoA)      i32 cx, cy, cz                                                          (:174-193)
 //   RT_KAT_BIND       p3 d3 lo3 hi3                                   p3 after the clamps                                                     (:265-322)
 //   RT_KAT_POW        f32 x                                           (float)pow(0.5f, x), NaN -> 1                                           (:631-632)
+//   RT_KAT_QUOTIENT   f32 plane, o, d                                 f32 (plane-o)/d as the compiler divides, f32 the walk's short sequence, u32 tame (:383-385)
 #include "rt_devfuncs.h"
 #include "raytrace_hip.h"
 
@@ -99,6 +100,13 @@ __global__ __launch_bounds__(256) void rt_kat_kernel(int op, uint32_t count, con
     case RT_KAT_POW:
         fo[0] = half_falloff(fi[0]);
         break;
+    case RT_KAT_QUOTIENT: { // both ways of wf_trace_kernel's walk; they must agree (up to the sign of zero) whenever `tame` says so
+        const float plane = fi[0], o = fi[1], d = fi[2];
+        fo[0] = (plane - o) / d;
+        fo[1] = tame_quotient(plane - o, d, refined_rcp(d));
+        reinterpret_cast<uint32_t *>(fo)[2] = (tame_origin(plane) && tame_origin(o) && tame_direction(d)) ? 1u : 0u;
+        break;
+    }
     default:
         break;
     }
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256) void rt_kat_kernel(int op, uint32_t count, con
 
 extern "C" int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint inStride, void *out, cl_uint outStride, const float *table)
 {
-    static const uint32_t inNeed[RT_KAT_OPS] = { 8, 16, 4, 68, 36, 12, 48, 4 }, outNeed[RT_KAT_OPS] = { 192, 24, 4, 20, 4, 12, 12, 4 };
+    static const uint32_t inNeed[RT_KAT_OPS] = { 8, 16, 4, 68, 36, 12, 48, 4, 12 }, outNeed[RT_KAT_OPS] = { 192, 24, 4, 20, 4, 12, 12, 4, 12 };
     if (op < 0 || op >= RT_KAT_OPS || !in || !out || inStride < inNeed[op] || outStride < outNeed[op] || (inStride & 3u) || (outStride & 3u)) return -1;
     if (op == RT_KAT_BOX && !table) return -1;
     if (count == 0) return 0;

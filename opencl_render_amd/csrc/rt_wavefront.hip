@@ -171,27 +171,6 @@ __device__ __forceinline__ uint32_t resolve_hit(const RtDevScene &S, unsigned lo
     return __float_as_uint(r0.w);
 }
 
-// Exponent ranges in which the division (plane - o) / d needs neither operand scaling nor a fix-up (wf_trace_kernel's walk): a
-// plane or origin coordinate is 0 or 2^-60 <= |x| <= 2^39, so n = plane - o is 0 or 2^-84 <= |n| <= 2^40; 2^-40 <= |d| <= 2^40.
-// Then exponent(n) - exponent(d) < 96, neither d, 1/d nor n/d is subnormal, and n is not tiny (the conditions of v_div_scale_f32),
-// and v_div_fixup_f32 returns the quotient it is given (the sign of a zero quotient does not matter: these values are only compared).
-__device__ __forceinline__ bool tame_origin(float x)
-{
-    const float m = __builtin_fabsf(x);
-    return (m == 0.f) | ((m >= 0x1p-60f) & (m <= 0x1p39f));
-}
-__device__ __forceinline__ bool tame_direction(float x)
-{
-    const float m = __builtin_fabsf(x);
-    return (m >= 0x1p-40f) & (m <= 0x1p40f);
-}
-// r1 of the compiler's division sequence: v_rcp_f32, then fma(fma(-d, r0, 1), r0, r0)
-__device__ __forceinline__ float refined_rcp(float dd)
-{
-    const float r0 = __builtin_amdgcn_rcpf(dd);
-    return __builtin_fmaf(__builtin_fmaf(-dd, r0, 1.f), r0, r0);
-}
-
 // Order of the hits of one ray inside a test phase: earlier recorded cell, then smaller t, then earlier candidate.
 __device__ __forceinline__ unsigned long long hit_key(uint32_t cellOrder, float t, uint32_t pair)
 {
@@ -1252,10 +1231,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                             float nd;                                                                                               \
                             if (FAST) {                                                                                             \
                                 const float rr = sxm ? rx : (sym ? ry : rz);                                                        \
-                                const float nn = plane - oo;                                                                        \
-                                const float q0 = nn * rr;                                                                           \
-                                const float q1 = __builtin_fmaf(__builtin_fmaf(-dd, q0, nn), rr, q0);                               \
-                                nd = __builtin_fmaf(__builtin_fmaf(-dd, q1, nn), rr, q1);                                           \
+                                nd = tame_quotient(plane - oo, dd, rr);                                                             \
                             } else nd = (plane - oo) / dd;                                                                          \
                             dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;                                     \
                         }                                                                                                           \

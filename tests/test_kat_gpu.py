@@ -93,3 +93,52 @@ def test_device_half_attenuation_pow(kat):
     assert ulp.max() <= 1, f"max {ulp.max()} ULP"
     assert (ulp == 0).mean() >= 0.999, f"{(ulp != 0).sum()} of {len(ulp)} vectors differ by 1 ULP"
     assert got[kat["pow_x"] == 0][0] == 1.0
+
+
+QUOTIENT = 8
+
+
+def test_device_walk_quotient_short_sequence_is_the_division():
+    """wf_trace_kernel's walk computes (plane - o) / d -- the correctly rounded quotient the reference's C division gives
+    (raytrace_opencl.c:383-385) -- and, for waves whose operands have tame exponents, a 5-instruction sequence that is the
+    compiler's division minus the scaling / fix-up instructions.  Both run here on 3 M operand triples: wherever the kernel's own
+    `tame` predicate holds the two must agree bit for bit (a zero may differ in sign: the values are only ever compared), and
+    the division itself must be IEEE (numpy float32).  Operands: log-uniform over the whole tame range, exponents at both ends
+    of it, differences of neighbouring floats, exact zeros, significands of all ones."""
+    rng = np.random.default_rng(2024)
+    n = 1_000_000
+
+    def mag(lo, hi, k):  # sign * 2^U(lo,hi) with a random significand
+        e = rng.uniform(lo, hi, k)
+        return (np.exp2(e) * rng.choice([-1.0, 1.0], k)).astype(np.float32)
+
+    plane = mag(-60, 39, 3 * n)
+    o = mag(-60, 39, 3 * n)
+    d = mag(-40, 40, 3 * n)
+    # second million: origins close to their plane (the common case on a walk), incl. neighbours and equal values
+    plane[n:2 * n] = mag(-8, 8, n)
+    ulps = rng.integers(-4, 5, n)
+    o[n:2 * n] = (plane[n:2 * n].view(np.int32) + ulps.astype(np.int32)).view(np.float32)
+    # third million: the ends of the ranges, zeros, all-ones significands
+    ends = np.array([2.0 ** -60, 2.0 ** 39, -(2.0 ** -60), -(2.0 ** 39), 0.0, np.float32(2.0 ** 39) * np.float32(1 - 2.0 ** -24)], np.float32)
+    dends = np.array([2.0 ** -40, 2.0 ** 40, -(2.0 ** -40), -(2.0 ** 40), np.float32(2.0 ** -39) * np.float32(1 - 2.0 ** -24), 1.0, 3.0], np.float32)
+    plane[2 * n:] = rng.choice(ends, n)
+    o[2 * n:] = np.where(rng.random(n) < 0.5, rng.choice(ends, n), o[2 * n:])
+    d[2 * n:] = np.where(rng.random(n) < 0.5, rng.choice(dends, n), (d[2 * n:].view(np.uint32) | np.uint32(0x7fffff)).view(np.float32))
+    inp = np.stack([plane, o, d], axis=1).astype(np.float32)
+    out = run(QUOTIENT, inp, 12)
+    exact = out[:, 0:4].copy().view(np.float32).reshape(-1)
+    short = out[:, 4:8].copy().view(np.float32).reshape(-1)
+    tame = out[:, 8:12].copy().view(np.uint32).reshape(-1)
+    assert tame.mean() > 0.99  # the operands were drawn from the tame ranges (all-ones significands at the very end fall out)
+    with np.errstate(all="ignore"):
+        want = ((plane - o).astype(np.float32) / d).astype(np.float32)
+    assert exact.tobytes() == want.tobytes(), "the device division is not the IEEE quotient"
+    t = tame == 1
+    same = (exact.view(np.uint32) == short.view(np.uint32)) | ((exact == 0) & (short == 0))
+    bad = np.flatnonzero(t & ~same)
+    assert bad.size == 0, f"short sequence differs on {bad.size} tame triples, first {inp[bad[0]]}: {exact[bad[0]]!r} vs {short[bad[0]]!r}"
+    # and the predicate refuses what the short sequence cannot do
+    wild = np.array([[1.0, 0.5, 0.0], [1.0, 0.5, 1e-30], [1e30, 0.5, 1.0], [1.0, 1e-25, 1.0], [np.inf, 0.0, 1.0], [1.0, np.nan, 1.0],
+                     [1.0, 0.5, np.inf], [1.0, 0.5, 2.0 ** 41]], np.float32)
+    assert not run(QUOTIENT, wild, 12)[:, 8:12].copy().view(np.uint32).any()

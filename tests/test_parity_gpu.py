@@ -202,6 +202,7 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
     {"RT_WF_REGION_RAYS": "1", "RT_WF_APPEND_RAYS": "0"},   # every round cut at region boundaries and traced region by region
     {"RT_WF_REGION_RAYS": "1", "RT_WF_APPEND_RAYS": "0", "RT_WF_EXTRA_FACTOR": "1", "RT_WF_LOOKAHEAD": "0"},  # ... with a region B that overflows
     {"RT_WF_REGION_RAYS": "4000000000"},                   # never
+    {"RT_WF_FAST_QUOTIENT": "0"},                          # every wave divides the long way (the default picks per wave: test_kat_gpu.py)
 ])
 def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
     """Ray segmentation (the DDA state at a ray parameter is computed without walking, segments are traced independently and
