@@ -253,12 +253,9 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
     if (born) {
         W.rng[a] = rng;
         W.meta[a] = make_uint4(outSlot, localPixel, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), hit_tri);
-        W.outc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 *ringA = W.ring + (size_t)a * (RT_RING * 3); // ring slot 0 = the camera ray (:490-508)
-        ringA[0] = pack4(ld3(S.eye), 0.f);
-        ringA[1] = pack4(dir, __uint_as_float(RT_NONE));
-        ringA[2] = make_float4(1.f, 1.f, 1.f, __uint_as_float((12u << 1) | 1u)); // maxBounces 12, fromCamera (:492,:505)
-        W.reqX[0][a] = make_uint2(RT_NONE, a);
+        // ring slot 0 = the camera ray (:490-508).  Only its direction is stored: round 0 of wf_logic_kernel, the slot's one
+        // reader, knows the rest (origin = eye, weight 1, maxBounces 12, fromCamera), as it knows that nothing is collected yet.
+        W.ring[(size_t)a * (RT_RING * 3) + 1] = pack4(dir, __uint_as_float(RT_NONE));
         W.res[a] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
     }
 }
@@ -393,7 +390,8 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
             TriRow row;
             row.tri = RT_NONE;
             if (FIRST) {
-                c0 = ringA[0]; c1 = ringA[1]; c2 = ringA[2]; // slot 0 = the camera ray
+                // slot 0 = the camera ray, of which wf_primary_kernel stores the direction only (:490-508: origin = eye, weight 1, maxBounces 12, fromCamera)
+                c0 = pack4(ld3(S.eye), 0.f); c1 = ringA[1]; c2 = make_float4(1.f, 1.f, 1.f, __uint_as_float((12u << 1) | 1u));
                 load_tri_row(S, res_tri, row);
             } else out = xyz(W.outc[a]);
             uint32_t hit_tri = meta.w;
