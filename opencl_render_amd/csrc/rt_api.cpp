@@ -580,7 +580,7 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
             sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
             sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
             sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
-            sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
+            sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint8_t>(ecap, &Wf.sortTag) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
             sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
             sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
             sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal) ||

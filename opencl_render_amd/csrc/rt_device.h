@@ -168,7 +168,8 @@ struct RtWavefront {
     uint4 *stageEnt;           // [2*capacity + extraCap][4] entries, {.., cell | (bin | copy<<6)<<24, ..} .. {.., rank in workgroup | segment<<24}
     uint4 *sortedEnt;          // [2*capacity + extraCap][4] the entries of an APPENDED round (small rounds skip the sort), same layout
     uint32_t *sortedIdx;       // [2*capacity + extraCap] a SORTED round: index into stageEnt of the entry at each sorted position
-    uint32_t *sortRank;        // [2*capacity + extraCap] rank of the entry inside its (bin, copy) class
+    uint32_t *sortRank;        // [2*capacity + extraCap] rank of the entry inside its (bin, copy) class; 0xffffffff = an unused reservation
+    uint8_t *sortTag;          // [2*capacity + extraCap] the class: bin | copy << 6 (what wf_scatter_kernel needs of an entry, 5 bytes instead of a 64-byte line)
     uint32_t *sortExtra;       // [1] entries in region B this round
     uint32_t extraCap;         // capacity of region B (multiple of 256)
     uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round

@@ -920,11 +920,15 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         for (uint32_t w = 0; w < wave; ++w) before += extraWave[w];
         if (extraBase == 0xffffffffu) { // no room: this workgroup's rays stay whole
             uint4 *ent = append ? W.sortedEnt : W.stageEnt;
-            for (uint32_t i = extraVoidAt + threadIdx.x; i < extraVoidEnd; i += 256) ent[4 * (size_t)(2u * W.capacity + i)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            for (uint32_t i = extraVoidAt + threadIdx.x; i < extraVoidEnd; i += 256) {
+                ent[4 * (size_t)(2u * W.capacity + i)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+                W.sortRank[2u * W.capacity + i] = 0xffffffffu;
+            }
             if (nseg > 1) nseg = 1;
         }
         else extraAt = 2u * W.capacity + extraBase + before; // region B of the entry arrays starts after the 2*capacity queue slots
     }
+    uint32_t rank0 = 0, bin0 = 0; // sorted mode: segment 0's class and its rank inside this workgroup
     uint32_t appendAt = 0; // append mode: where segment 0 of this lane's ray goes
     if (append) {
         const unsigned long long actMask = __ballot(active);
@@ -980,6 +984,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
             continue;
         }
         const uint32_t rank = atomicAdd(&binCount[bin], 1u);
+        if (k == 0) { rank0 = rank; bin0 = bin; }
         uint4 *e = W.stageEnt + 4 * (size_t)(k == 0 ? mine : extraAt + k - 1);
         e[0] = make_uint4(mine, cur.cell | ((bin | (copy << 6)) << 24), segEnd, excluded);
         e[1] = make_uint4(__float_as_uint(cur.dx), __float_as_uint(cur.dy), __float_as_uint(cur.dz), __float_as_uint(tmin));
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank | (k << 24)); // rank inside this workgroup's bin for now
         cur = nxt;
         if (last) { // unused tail of the reservation: empty entries the scatter kernel drops
-            for (uint32_t r = k + 1; r < nseg; ++r) W.stageEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            for (uint32_t r = k + 1; r < nseg; ++r) { W.stageEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u); W.sortRank[extraAt + r - 1] = 0xffffffffu; }
             break;
         }
     }
@@ -998,13 +1003,16 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
         binBase[threadIdx.x] = n ? atomicAdd(&W.sortHist[copy * RT_WF_SORT_BINS + threadIdx.x], n) : 0u;
     }
     __syncthreads();
-    // second visit: rank inside the (bin, copy) class = this workgroup's base + rank inside the workgroup
-    for (uint32_t k = 0; k < nseg; ++k) {
-        uint4 *e = W.stageEnt + 4 * (size_t)(k == 0 ? mine : extraAt + k - 1);
+    // second visit: rank inside the (bin, copy) class = this workgroup's base + rank inside the workgroup.  Segment 0's numbers
+    // are still in registers (most rays have no other: reading the entry back would wait for its own stores and a round trip).
+    if (nseg) { W.sortRank[mine] = binBase[bin0] + rank0; W.sortTag[mine] = (uint8_t)(bin0 | (copy << 6)); }
+    for (uint32_t k = 1; k < nseg; ++k) {
+        uint4 *e = W.stageEnt + 4 * (size_t)(extraAt + k - 1);
         const uint32_t tag = e[0].y >> 24;
         if (e[0].x == 0xffffffffu) break;
         const uint32_t w = e[3].w;
-        W.sortRank[k == 0 ? mine : extraAt + k - 1] = binBase[tag & 63u] + (w & 0xffffffu);
+        W.sortRank[extraAt + k - 1] = binBase[tag & 63u] + (w & 0xffffffu);
+        W.sortTag[extraAt + k - 1] = (uint8_t)tag;
     }
     } // items
 }
@@ -1064,10 +1072,10 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
         }
         if (valid) {
             // only the ORDER is written: the trace kernel gathers its 64-byte entries from the staging array through it
-            const uint2 e0 = *reinterpret_cast<const uint2 *>(W.stageEnt + 4 * (size_t)mine); // {request, cell | tag << 24}
-            if (e0.x != 0xffffffffu) { // not an unused reservation
-                const uint32_t tag = e0.y >> 24; // bin | copy << 6
-                W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + W.sortRank[mine]] = mine;
+            const uint32_t rank = W.sortRank[mine];
+            if (rank != 0xffffffffu) { // not an unused reservation
+                const uint32_t tag = W.sortTag[mine]; // bin | copy << 6
+                W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + rank] = mine;
             }
         }
     }
