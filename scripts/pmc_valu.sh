@@ -13,7 +13,7 @@ calls = collections.Counter()
 for f in glob.glob(sys.argv[1] + "/run/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         rows[k][r["Counter_Name"]] += float(r["Counter_Value"])
         d = (k, r["Dispatch_Id"])
         if d not in seen: seen.add(d); calls[k] += 1

@@ -19,4 +19,5 @@ pass sq4k lambert_4k SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACT
 pass grbm4k lambert_4k GRBM_GUI_ACTIVE GRBM_COUNT
 python3 scripts/rank_share.py lambert_1m 1 2 4 8 > $out/rank_share_1m.txt 2>&1
 python3 scripts/rank_share.py lambert_4k 1 8 > $out/rank_share_4k.txt 2>&1
+bash scripts/pmc_valu.sh evidence > $out/valu_busy.txt 2>&1; cp gpurun_out/pmcv_evidence/valu.json $out/valu_busy.json
 ls $out
