@@ -105,6 +105,36 @@ def test_fresh_scenes_match_oracle(seed):
     assert_planes(got, want, f"fresh seed {seed}")
 
 
+def test_crowded_cells_take_the_flat_list_and_the_in_place_loop():
+    """The quantile grid keeps cells sparse (a soup has <= 4 candidates per cell), so crowded cells are made: stacks of identical
+    and of slightly shifted triangles.  Cells with 2-14 candidates put their further candidates on the trace kernel's per-wave
+    second list (which overflows here: 128 entries), cells with 15 or more read their exact count from the first further record
+    and loop in place (rt_device.h, pairRec).  Equal t among coincident candidates: the earliest list entry wins, as in the
+    reference's running maximum."""
+    sc = S.make_soup(320, 200, 3000, 0.05, seed=31, samples=2)
+    rng = np.random.default_rng(31)
+    verts, tris = [sc.vertex], [sc.tri_index]
+    base = sc.vertex_count
+    for stack, shift in ((40, 0.0), (14, 0.0), (9, 1e-4), (20, 3e-5)):
+        t = int(rng.integers(0, sc.triangle_count))
+        v = sc.vertex[sc.tri_index[t, :3]].copy()
+        v[:, :3] *= 6.0; v[:, :3] -= v[:, :3].mean(axis=0) * 0.8  # a big copy somewhere in view
+        for k in range(stack):
+            w = v.copy(); w[:, :3] += np.float32(shift * k)
+            verts.append(w); tris.append(np.array([[base, base + 1, base + 2, 0]], np.int32)); base += 3
+    n_new = sum(len(t) for t in tris[1:])
+    sc.vertex = np.concatenate(verts).astype(np.float32)
+    sc.tri_index = np.concatenate(tris).astype(np.int32)
+    sc.tri_material = np.concatenate([sc.tri_material, np.zeros(n_new, np.int32)])
+    sc.tri_uv = np.concatenate([sc.tri_uv, np.zeros((3 * n_new, 2), np.float32)])
+    sc.tri_normal = np.concatenate([sc.tri_normal, np.tile(sc.tri_normal[:3], (n_new, 1))])
+    R.build_lists(sc)
+    per_cell = np.diff(sc.grid_start.astype(np.int64))
+    assert per_cell.max() >= 40 and ((per_cell > 1) & (per_cell < 15)).sum() > 300 and (per_cell >= 15).sum() > 300
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    assert_planes(R.render_resident(sc, 0), want, "crowded cells")
+
+
 @pytest.mark.parametrize("name", ["mirror_hall", "mixed_materials_textured", "sparse_many_samples"])
 def test_megakernel_pipeline_matches_golden(name):
     """The single-launch variant (pipeline 0) ships too: same planes."""
