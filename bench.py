@@ -7,7 +7,8 @@
 A "step" is one frame: every rank renders its 128x128 tiles of the frame (one launch of the trace kernel over the
 scene resident in its HBM), the tile buffers are gathered to rank 0 (RCCL) and rank 0 scatters them into the three
 row-major u16 planes on its device.  Inputs are resident before the timed region; outputs stay on the device for
-`value` / `ms_per_step`; `ms_per_frame_with_d2h` is the same loop with the planes copied to pinned host memory every frame.
+`value` / `ms_per_step`; `ms_per_frame_with_d2h` is the same loop with the planes copied to pinned host memory every frame,
+`ms_per_frame_with_d2h_pipelined` the same with frame i's copy on a second stream under frame i+1's kernels.
 The same frame is split over more GPUs as N grows => "scaling": "strong".
 
 Workloads (synthetic seeded triangle soups, lists built by the library's host builders):
@@ -157,13 +158,13 @@ def main():
         ids_dev = torch.from_numpy(ids.reshape(-1)).to(device)
     L = R.lib()
 
-    def frame(to_host=None):
+    def frame(to_host=None, into=None):
         with torch.cuda.stream(work_stream):
             rs.render(stream)
             gathered = T.gather_tiles(tile_tensor, W, H, rank, world)
             if rank == 0:
                 # every pixel of the frame belongs to exactly one tile of the deal: the root writes its planes (no zero fill + add)
-                base = planes.data_ptr()
+                base = (planes if into is None else into).data_ptr()
                 rc = L.rtHipDetileStore(local_rank, gathered.data_ptr(), ids_dev.data_ptr(), world * slots, W, H,
                                         base, base + 2 * P, base + 4 * P, stream)
                 if rc != 0:
@@ -210,6 +211,40 @@ def main():
     torch.cuda.synchronize()
     barrier()
     ms_with_d2h = 1e3 * (time.perf_counter() - t1) / args.steps
+    # ---- and pipelined two deep: frame i's planes travel on a copy stream while frame i+1 renders into the other of two plane
+    # buffers (events both ways); every frame's planes are complete in pinned host memory when the clock stops.
+    ms_with_d2h_pipelined = None
+    if rank == 0:
+        copy_stream = torch.cuda.Stream(device)
+        dev2 = [planes, torch.zeros_like(planes)]
+        host2 = [host_planes, torch.empty(3 * P * 2, dtype=torch.uint8, pin_memory=True)]
+        rendered = [torch.cuda.Event(), torch.cuda.Event()]
+        copied = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def frame_pipelined(i):
+        b = i & 1
+        if rank == 0 and i >= 2:
+            work_stream.wait_event(copied[b])  # the buffer's previous frame has left the device
+        frame(into=dev2[b] if rank == 0 else None)
+        if rank == 0:
+            rendered[b].record(work_stream)
+            copy_stream.wait_event(rendered[b])
+            with torch.cuda.stream(copy_stream):
+                host2[b].copy_(dev2[b], non_blocking=True)
+            copied[b].record(copy_stream)
+
+    for i in range(2):
+        frame_pipelined(i)
+    torch.cuda.synchronize()
+    barrier()
+    t2 = time.perf_counter()
+    for i in range(args.steps):
+        frame_pipelined(i + 2)
+    torch.cuda.synchronize()
+    barrier()
+    ms_with_d2h_pipelined = 1e3 * (time.perf_counter() - t2) / args.steps
+    if rank == 0 and not (torch.equal(host2[0], host_planes) and torch.equal(host2[1], host_planes)):
+        sys.exit("bench.py: pipelined frames differ from the serial ones")
     if rs.finish():
         sys.exit("bench.py: a timed frame needed more rounds than its launch plan issued -- timing is void")
     if world > 1:
@@ -279,6 +314,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_frame_with_d2h": round(ms_with_d2h, 4),
+            "ms_per_frame_with_d2h_pipelined": round(ms_with_d2h_pipelined, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
