@@ -328,7 +328,8 @@ def main():
             "total_mrays_per_s": round(total_rays * args.steps / elapsed / 1e6, 3),
             "rays_per_frame": {"primary": int(primary_rays), "grid": int(total_stats["gridRays"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 5),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dom_name, "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(dom_bytes),
                          "frame": {"device_ms": round(kernel_ms, 4), "frames": int(launches), "algorithmic_bytes": int(b_local),
                                    "achieved": round(b_local / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,
