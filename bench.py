@@ -36,7 +36,8 @@ WORKLOADS = {
     "lambert_10m_4k": dict(width=3840, height=2160, triangles=10_000_000, edge=0.0013, kind="lambert"),
     "smoke": dict(width=256, height=256, triangles=10_000, edge=0.02, kind="lambert"),
 }
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0  # ... and the measured float4-copy ceiling (report both fractions)
 
 
 def log(*a):
