@@ -1,4 +1,4 @@
-# usage: bash scripts/xlogic.sh <tag>... -- timing experiments: per-launch durations of the first frame kernels with variants lib_<tag>.so
+# usage: bash scripts/xlogic.sh <tag>... -- per-launch durations of one frame's kernels (rocprofv3 --kernel-trace) for the in-tree library ("base") and variants lib_<tag>.so
 export TMPDIR=/tmp
 for tag in "$@"; do
   out=gpurun_out/xl_$tag; mkdir -p $out
