@@ -1317,12 +1317,16 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
             dgItems += items;
 #endif
             if (items) { // wave-uniform
-                volatile uint8_t *owners = ownerOf[wave];
-                volatile unsigned long long *keys = keyOf[wave];
-                volatile uint32_t *moreWho = moreOf[wave][0], *morePair = moreOf[wave][1];
+                // (the lists are addressed as the __shared__ arrays they are: through a generic `volatile` pointer every access became
+                // a system-coherent FLAT instruction with a wait behind it.  One wave, in-order LDS: a wavefront-scope fence is all the
+                // ordering the exchange between lanes needs, and it costs no instruction.)
+                uint8_t (&owners)[RT_WF_LEAN_LIST * 64] = ownerOf[wave];
+                unsigned long long (&keys)[64] = keyOf[wave];
+                uint32_t (&moreWho)[RT_WF_MORE_ITEMS] = moreOf[wave][0], (&morePair)[RT_WF_MORE_ITEMS] = moreOf[wave][1];
                 for (uint32_t j = 0; j < mineN; ++j) owners[myBase + j] = (uint8_t)lane;
                 keys[lane] = ~0ull;
                 if (lane == 0) moreCount[wave] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
                 for (uint32_t c0 = 0; c0 < items; c0 += 64) {
                     const uint32_t c = c0 + lane;
@@ -1368,9 +1372,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                                 }
                             }
                         }
-                        if (best != ~0ull) atomicMin((unsigned long long *)&keys[owner], best);
+                        if (best != ~0ull) atomicMin(&keys[owner], best);
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t more = min(moreCount[wave], (uint32_t)RT_WF_MORE_ITEMS);
                 for (uint32_t e0 = 0; e0 < more; e0 += 64) {
@@ -1388,9 +1393,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                         float t, l1, l2;
                         if (pair_test_flat(r0, r1, r2, r3, po, pd, ptmin, ptmax, pexcl, t, l1, l2))
-                            atomicMin((unsigned long long *)&keys[owner], hit_key(who >> 6, t, pair));
+                            atomicMin(&keys[owner], hit_key(who >> 6, t, pair));
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (mineN) {
                     const unsigned long long key = keys[lane];
