@@ -1324,7 +1324,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 unsigned long long (&keys)[64] = keyOf[wave];
                 uint32_t (&moreWho)[RT_WF_MORE_ITEMS] = moreOf[wave][0], (&morePair)[RT_WF_MORE_ITEMS] = moreOf[wave][1];
                 for (uint32_t j = 0; j < mineN; ++j) owners[myBase + j] = (uint8_t)lane;
-                keys[lane] = ~0ull;
+                {   // (made here, not kept in a register pair across the walk: the compiler spilled the hoisted constant to scratch)
+                    unsigned long long none = ~0ull;
+                    asm volatile("" : "+v"(none));
+                    keys[lane] = none;
+                }
                 if (lane == 0) moreCount[wave] = 0u;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations retire in order
