@@ -1,8 +1,9 @@
-"""One-off fuzz of the hot path against the CPU oracle (test infrastructure, like tests/): random materials (textures, bump maps,
-mirrors, transparency), random lights of every type, random soups -- usage: python scripts/fuzz_parity.py [first seed] [count]"""
+"""Fuzz of the hot path against the CPU oracle on the GPU box (not collected by pytest; the oracle stays under tests/): random
+materials (textures, bump maps, mirrors, transparency), random lights of every type, random soups.
+usage: python tests/fuzz_parity.py [first seed] [count]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import oracle_lib as O
 from opencl_render_amd import raytrace as R, scene as S
