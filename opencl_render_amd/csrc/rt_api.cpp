@@ -524,7 +524,7 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     const bool multiLight = D.lightCount > 1;
     sc->wfMultiLight = multiLight;
     // segment lengths by round size (rt_wavefront.hip, wf_setup_kernel); 4096 is longer than any walk = no cutting
-    uint32_t segLen[4] = { 4096u, 256u, 64u, 16u }, segRays[3] = { 700000u, 300000u, 30000u };
+    uint32_t segLen[5] = { 4096u, 384u, 96u, 64u, 16u }, segRays[4] = { 700000u, 300000u, 100000u, 30000u };
     auto parse_list = [](const char *b, uint32_t *out, int n) {
         for (int i = 0; i < n && b && *b; ++i) {
             char *endp = nullptr;
@@ -534,8 +534,8 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
             b = (*endp == ',') ? endp + 1 : endp;
         }
     };
-    parse_list(getenv("RT_WF_SEG"), segLen, 4);
-    parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 3);
+    parse_list(getenv("RT_WF_SEG"), segLen, 5);
+    parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 4);
     // rounds with at least this many rays are cut at region boundaries and traced region by region (rt_wavefront.hip, wf_setup_kernel)
     uint32_t regionRays = 0xffffffffu; // off by default: measured slower than length order once a cell visit is one fabric request
     if (const char *b = getenv("RT_WF_REGION_RAYS")) regionRays = (uint32_t)strtoul(b, nullptr, 10);
@@ -563,8 +563,8 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         Wf.capacity = (uint32_t)cap;
         Wf.shardCap = (uint32_t)shardCap;
         Wf.lookAhead = lookAhead;
-        for (int i = 0; i < 4; ++i) Wf.segLen[i] = segLen[i];
-        for (int i = 0; i < 3; ++i) Wf.segRays[i] = segRays[i];
+        for (int i = 0; i < 5; ++i) Wf.segLen[i] = segLen[i];
+        for (int i = 0; i < 4; ++i) Wf.segRays[i] = segRays[i];
         Wf.appendRays = appendRays;
         Wf.regionRays = regionRays;
         const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)

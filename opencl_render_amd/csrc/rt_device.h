@@ -133,8 +133,8 @@ struct RtWavefront {
     uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (RT_WF_SPIN_LIMIT, default 16384)
     uint32_t *hostStatus;    // pinned HOST words mapped into the device (RT_WF_STATUS_*): written by kernels, read by the host after a sync
     uint32_t *roundLog;      // [RT_WF_ROUND_LOG] entries (all segments) the trace kernel of round r found, for sizing later frames' launches
-    uint32_t segLen[4];      // aimed-at cell visits per segment for rounds with >= segRays[0] | >= segRays[1] | >= segRays[2] | fewer rays
-    uint32_t segRays[3];     // (RT_WF_SEG="a,b,c,d", RT_WF_SEG_RAYS="a,b,c"; defaults 4096,256,64,16 and 700000,300000,30000)
+    uint32_t segLen[5];      // aimed-at cell visits per segment for rounds with >= segRays[0] | >= segRays[1] | >= segRays[2] | >= segRays[3] | fewer rays
+    uint32_t segRays[4];     // (RT_WF_SEG="a,b,c,d,e", RT_WF_SEG_RAYS="a,b,c,d"; defaults 4096,384,96,64,16 and 700000,300000,100000,30000)
     // per-path state, indexed by path id
     unsigned long long *rng; // generator state (raytrace_opencl.c:474-481), already moved past the current hit's light draws
     unsigned long long *rngL; // lightCount > 1 only: where the current hit's NEXT light set-up draws from

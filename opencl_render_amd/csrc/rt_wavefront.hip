@@ -757,10 +757,13 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
     __shared__ uint32_t extraWave[4], extraBase, extraVoidAt, extraVoidEnd, raysWave[4], longWave[4], actWave[4], actBase;
+    __shared__ uint32_t sliceCount[RT_WF_QSHARDS]; // the queue lengths, read once (a work item's own length was a second dependent load)
+    static_assert(RT_WF_QSHARDS == 512, "two queue lengths per thread");
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     { // rays of the whole round and the longest queue slice: RT_WF_QSHARDS queue lengths, two per thread
         const uint32_t c0 = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x], c1 = W.counts[(round % 3) * RT_WF_QSHARDS + 256 + threadIdx.x];
+        sliceCount[threadIdx.x] = c0; sliceCount[256 + threadIdx.x] = c1;
         uint32_t n = c0 + c1, m = max(c0, c1);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { n += __shfl_xor(n, off, 64); m = max(m, (uint32_t)__shfl_xor((int)m, off, 64)); }
@@ -769,7 +772,8 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     __syncthreads();
     const uint32_t roundRays = raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3];
     const uint32_t longest = max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3]));
-    const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : (roundRays >= W.segRays[2] ? W.segLen[2] : W.segLen[3]));
+    const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : (roundRays >= W.segRays[2] ? W.segLen[2] :
+                            (roundRays >= W.segRays[3] ? W.segLen[3] : W.segLen[4])));
     // A small round is cut into near-equal segments; ordering those by length buys nothing, and the two launches of the
     // counting sort are a fixed ~50 us.  Such a round's entries are APPENDED straight to the trace input instead: segment 0 of
     // every ray compactly at the front (sortTotal counts them), further segments in region B (sortExtra counts them), and
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     for (uint32_t item = blockIdx.x; item < RT_WF_QSHARDS * usedBlocks; item += gridDim.x) {
     const uint32_t shard = item % RT_WF_QSHARDS;
     const uint32_t local0 = (item / RT_WF_QSHARDS) * 256;
-    const uint32_t total = W.counts[(round % 3) * RT_WF_QSHARDS + shard];
+    const uint32_t total = sliceCount[shard];
     if (local0 >= total) continue; // workgroup-uniform: this slice is shorter
     __syncthreads(); // the previous item's LDS counters have been read by everybody
     if (threadIdx.x < RT_WF_SORT_BINS) binCount[threadIdx.x] = 0u;
@@ -900,9 +904,14 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
             if ((int)lane >= off) incl += up;
         }
         if (lane == 63) extraWave[wave] = incl;
+        const unsigned long long actMask0 = __ballot(active);
+        if (lane == 0) actWave[wave] = (uint32_t)__popcll(actMask0);
         __syncthreads();
         const uint32_t sum = extraWave[0] + extraWave[1] + extraWave[2] + extraWave[3];
         if (threadIdx.x == 0) {
+            // (an appended round's second atomic -- where segment 0 of this workgroup's rays goes -- travels with the first)
+            uint32_t appendBase = 0;
+            if (append) appendBase = atomicAdd(&W.sortTotal[0], actWave[0] + actWave[1] + actWave[2] + actWave[3]);
             // A reservation is never undone (an add followed by a subtract is not atomic across workgroups: a later, smaller
             // reservation could land inside the range the subtract gives back).  A count past extraCap just means "region B is
             // full"; every reader clamps it.  The one workgroup whose range straddles the end owns [at, extraCap) and marks
@@ -914,6 +923,7 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
                 at = 0xffffffffu;
             }
             extraBase = at;
+            actBase = appendBase;
         }
         __syncthreads();
         uint32_t before = incl - mineExtra;
@@ -932,10 +942,6 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     uint32_t appendAt = 0; // append mode: where segment 0 of this lane's ray goes
     if (append) {
         const unsigned long long actMask = __ballot(active);
-        if (lane == 0) actWave[wave] = (uint32_t)__popcll(actMask);
-        __syncthreads();
-        if (threadIdx.x == 0) actBase = atomicAdd(&W.sortTotal[0], actWave[0] + actWave[1] + actWave[2] + actWave[3]);
-        __syncthreads();
         appendAt = actBase + (uint32_t)__popcll(actMask & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < wave; ++w) appendAt += actWave[w];
     }
