@@ -43,7 +43,7 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
 extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t rtw_launch_status(const RtWavefront *wf, uint32_t round, hipStream_t stream);
 extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
-extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, int appendedPlan, hipStream_t stream);
 
 namespace {
 
@@ -183,12 +183,14 @@ struct rtHipScene {
         // launch plan (render_wavefront): what the last discovery frame needed
         uint32_t roundsNeeded = 0;
         uint32_t planEntries[RT_WF_ROUND_LOG] = { 0 }, planEntriesNext[RT_WF_ROUND_LOG] = { 0 };
+        uint32_t planSorted[RT_WF_ROUND_LOG] = { 0 }, planSortedNext[RT_WF_ROUND_LOG] = { 0 }; // != 0: some batch's round went through the counting sort
     };
     std::vector<Group> groups;
     hipEvent_t forkEvent = nullptr;
     uint32_t samplesPerBatch = 1;
     uint32_t planRounds = 0;   // rounds a planned frame issues per batch; 0 = no plan yet (the next frame is a discovery frame)
     bool blocking = false;     // RT_WF_BLOCKING=1: every frame watches the queue (no plan)
+    bool planNoScatter = false; // RT_WF_PLAN_SORT=skip (test hook): planned frames claim every round was appended, so that the sorted-after-all path runs
     bool planGridTiny = false; // RT_WF_PLAN_GRID=tiny (test hook): planned trace grids of one workgroup, so that the too-small-grid path runs
     uint32_t planCap = 0;      // RT_WF_PLAN_ROUNDS=n (test hook): planned frames issue at most n rounds, so that the too-short-plan path runs
     bool unverified = false;   // planned frames were issued since the last frame_finish()
@@ -606,6 +608,7 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');
     if (const char *b = getenv("RT_WF_PLAN_ROUNDS")) sc->planCap = (uint32_t)strtoul(b, nullptr, 10);
     if (const char *b = getenv("RT_WF_PLAN_GRID")) sc->planGridTiny = (strcmp(b, "tiny") == 0);
+    if (const char *b = getenv("RT_WF_PLAN_SORT")) sc->planNoScatter = (strcmp(b, "skip") == 0);
     const char *env = getenv("RT_HIP_PIPELINE");
     if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
     return 0;
@@ -718,7 +721,10 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
     auto issue_round = [&](rtHipScene::Group &G, hipStream_t on) -> int {
         const uint32_t r = G.rounds;
         if (r > 0) { // the requests appended by logic(r-1): order them, then walk the grid
-            HIP_OK(stage(4, on, [&] { return rtw_launch_sort(&G.dev, &G.wf, r, G.queueBlocks, on); }));
+            // a planned round whose entries were appended last time needs no scatter launch (wf_setup_kernel raises RT_WF_ERR_GRID if
+            // the round is big enough to be sorted after all: the frame is then rendered again, watched)
+            const int appendedPlan = (planned && r < RT_WF_ROUND_LOG && G.planEntries[r] && (!G.planSorted[r] || sc->planNoScatter)) ? 1 : 0;
+            HIP_OK(stage(4, on, [&] { return rtw_launch_sort(&G.dev, &G.wf, r, G.queueBlocks, appendedPlan, on); }));
             HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, r, trace_blocks(G, r), on); }));
         }
         HIP_OK(stage(1, on, [&] { return rtw_launch_logic(&G.dev, &G.wf, r, G.logicBlocks, on); }));
@@ -780,10 +786,13 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
                 HIP_OK(hipStreamSynchronize(on));
                 uint32_t needed = 1; // logic(0) always runs
                 for (uint32_t r = 1; r < std::min<uint32_t>(G.rounds, RT_WF_ROUND_LOG); ++r)
-                    if (log[r]) needed = r + 1;
+                    if (log[r] & 0x7fffffffu) needed = r + 1;
                 if (G.rounds > RT_WF_ROUND_LOG) needed = G.rounds;
                 G.roundsNeeded = std::max(G.roundsNeeded, needed);
-                for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) G.planEntriesNext[r] = std::max(G.planEntriesNext[r], log[r]);
+                for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) { // (bit 31 of a logged size: the round's entries were appended, not sorted)
+                    G.planEntriesNext[r] = std::max(G.planEntriesNext[r], log[r] & 0x7fffffffu);
+                    if ((log[r] & 0x7fffffffu) && !(log[r] >> 31)) G.planSortedNext[r] = 1u;
+                }
             }
             rounds = std::max<uint64_t>(rounds, G.rounds);
             if (sampleCount > 1) // a one-sample frame's pixels were written by the kernels that finished them
@@ -800,6 +809,8 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
             need = std::max(need, G.roundsNeeded);
             memcpy(G.planEntries, G.planEntriesNext, sizeof G.planEntries);
             memset(G.planEntriesNext, 0, sizeof G.planEntriesNext);
+            memcpy(G.planSorted, G.planSortedNext, sizeof G.planSorted);
+            memset(G.planSortedNext, 0, sizeof G.planSortedNext);
             G.roundsNeeded = 0;
         }
         sc->planRounds = sc->planCap ? std::min(need, sc->planCap) : need;

@@ -752,7 +752,9 @@ __device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t 
     return pos ? c0 + (uint32_t)m : c0 - (uint32_t)m;
 }
 
-__global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+// appendedPlan: the host issued no wf_scatter_kernel behind this launch, because this round's entries were appended when the frame
+// was last rendered (rt_api.cpp); if the round has to be sorted after all, the host is told and renders the frame again.
+__global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round, const uint32_t appendedPlan)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
@@ -780,6 +782,10 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
     // wf_scatter_kernel finds nothing to do.
     const bool append = roundRays < W.appendRays;
     if (append && blockIdx.x == 0 && threadIdx.x == 0) W.sortTotal[1] = RT_WF_ORDER_APPENDED; // tells the trace kernel that region B is in use
+    if (!append && appendedPlan) { // nothing will order this round's entries (sortTotal stays 0: the trace kernel finds nothing to do)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+        return;
+    }
     // A BIG round is bound by the rate at which L2 misses are served (profiles/r02_*: 36 M 128-byte fabric requests per frame at
     // ~90 % of the measured random-gather ceiling): its rays meet the same cells at unrelated times, so nearly every cell visit
     // misses L2.  Such a round is cut at REGION boundaries instead (a region = 64^3 cells, 1/64 of the grid: ~2 MB of pair
@@ -1138,7 +1144,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // through ONE contiguous eighth of the region-ordered entries and its L2 holds the one or two regions it is in.
     const uint32_t blocksUsed = (chunksA + chunksB + 3u) >> 2;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (round < RT_WF_ROUND_LOG) W.roundLog[round] = total + extra;
+        if (round < RT_WF_ROUND_LOG) W.roundLog[round] = (total + extra) | (appended ? 0x80000000u : 0u); // (bit 31: not sorted)
     }
     const uint32_t perXcd = (blocksUsed + 7u) >> 3;
     const uint32_t slots = (order == RT_WF_ORDER_REGION) ? 8u * perXcd : blocksUsed; // work items the grid has to cover
@@ -1503,10 +1509,10 @@ extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefron
 }
 
 // setup + scatter of one round's requests: fixed grids, the kernels stride over the blocks that are in use
-extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, int appendedPlan, hipStream_t stream)
 {
-    hipLaunchKernelGGL(wf_setup_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
-    hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round);
+    hipLaunchKernelGGL(wf_setup_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, (uint32_t)(appendedPlan ? 1 : 0));
+    if (!appendedPlan) hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round);
     return hipGetLastError();
 }
 

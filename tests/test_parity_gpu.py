@@ -416,6 +416,26 @@ def test_planned_trace_grid_that_is_too_small_is_noticed(monkeypatch):
         rs.close()
 
 
+def test_planned_round_that_has_to_be_sorted_after_all_is_noticed(monkeypatch):
+    """A planned frame issues no scatter launch for a round whose entries were appended (not sorted) when the frame was last
+    rendered.  Should such a round be big enough for the counting sort after all (forced here: the plan claims every round was
+    appended, and RT_WF_APPEND_RAYS=0 sorts them all), wf_setup_kernel tells the host and finish() renders the frame again."""
+    monkeypatch.setenv("RT_WF_PLAN_SORT", "skip")
+    monkeypatch.setenv("RT_WF_APPEND_RAYS", "0")
+    sc = S.make_soup(320, 200, 20_000, 0.03, seed=43, samples=1)
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        assert not rs.finish()
+        rs.render()
+        assert rs.finish() is True
+        assert_planes(rs.readback(), want, "frame redone after a round that had to be sorted")
+    finally:
+        rs.close()
+
+
 def test_primary_only_frames_issue_no_empty_rounds():
     """BASELINE config 2 (luminance-only material, no lights): no path ever waits for the grid, so the plan of a later frame is
     primary + one logic round -- no sort / trace launches at all."""
