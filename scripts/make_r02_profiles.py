@@ -79,7 +79,8 @@ valu = p["SQ_INSTS_VALU"] / 1024 * 4
 reading = ("GRBM_GUI_ACTIVE sums the 8 XCDs: /8 = cycles the kernel took. SQ_INSTS_VALU / 1024 SIMDs x 4 cycles per wave64 instruction = cycles of "
            "VALU issue per SIMD. Their ratio is the share of the kernel's duration in which every SIMD was issuing vector instructions: at ~1.0 "
            "the kernel sits on its instruction-issue floor (an earlier reading added 12 cycles for each of a wave's 76 32-bit multiplies as "
-           "quarter-rate instructions; with the kernel at this speed that sum would exceed its duration, so they cannot cost that much here).")
+           "quarter-rate instructions; with the kernel at this speed that sum would exceed its duration, so they cannot cost that much here).  "
+           "The two counters come from separate profiler passes: a ratio a few percent either side of 1 is their run-to-run noise.")
 json.dump({"workload": "lambert_4k", "commit": commit, "kernel": "wf_primary_kernel", "per_frame": p, "reading": reading,
            "derived": {"kernel_cycles": round(cyc), "valu_issue_cycles_per_simd": round(valu), "valu_busy_fraction": round(valu / cyc, 3),
                        "instructions_per_wave": round(p["SQ_INSTS_VALU"] / p["SQ_WAVES"], 1)}},
