@@ -649,7 +649,11 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                 if (S.sampleCount == 1u) store_single_sample(S, meta.y, out);
                 else W.sampleOut[meta.x] = pack4(out, 0.f);
             } else {
-                // park the path in HBM until the grid has answered
+                // park the path in HBM until the grid has answered.  The index is made opaque here so that the store addresses are
+                // worked out again (two instructions each) instead of being the prologue's load addresses kept alive across the
+                // whole state machine: those were spilled, and every reload put an `s_waitcnt vmcnt(0)` -- i.e. "all stores so far
+                // acknowledged" -- between two stores (ten of them in a row: a third of a later round's time).
+                asm volatile("" : "+v"(a));
                 if (rngDirty) W.rng[a] = rng;
                 if (outDirty) W.outc[a] = pack4(out, 0.f);
                 W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | ((attStored ? 1u : 0u) << 9) |
@@ -671,6 +675,7 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
         wave_append2(&countOut[shard], emit, &countOut[RT_WF_SHARDS + shard], emitLa, slot, slotLa);
         slot += shard * W.shardCap;
         slotLa += (RT_WF_SHARDS + shard) * W.shardCap;
+        asm volatile("" : "+v"(a), "+v"(slot), "+v"(slotLa)); // (same for the request stores: addresses made here, not carried)
         if (slot != 0xfffffff0u) DG(8);
         if (emit) {
             W.reqO[outq][slot] = pack4(ro, rtmin);
