@@ -345,9 +345,10 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
     // main requests only (slices [0, RT_WF_SHARDS)): one per waiting path; look-ahead answers are picked up by index.
     // The grid is a whole number of waves per slice (rtw_launch_logic), so a wave stays in ONE slice and needs its length only:
     // slice = wave id % RT_WF_SHARDS, chunks of 64 entries dealt to the slice's waves in turn.
-    const uint32_t shard = waveId % RT_WF_SHARDS;
-    const uint32_t total = countIn[shard];
-    for (uint32_t localChunk = waveId / RT_WF_SHARDS; localChunk * 64 < total; localChunk += waves / RT_WF_SHARDS) {
+    // (wave-uniform values are told to be so: they live in scalar registers, not in one of the few vector registers left)
+    const uint32_t shard = __builtin_amdgcn_readfirstlane(waveId % RT_WF_SHARDS);
+    const uint32_t total = __builtin_amdgcn_readfirstlane(countIn[shard]);
+    for (uint32_t localChunk = __builtin_amdgcn_readfirstlane(waveId / RT_WF_SHARDS); localChunk * 64 < total; localChunk += waves / RT_WF_SHARDS) {
         const uint32_t local = localChunk * 64 + lane;
         const uint32_t q = shard * W.shardCap + local;
         const bool live = local < total;
