@@ -105,6 +105,19 @@ def test_fresh_scenes_match_oracle(seed):
     assert_planes(got, want, f"fresh seed {seed}")
 
 
+@pytest.mark.parametrize("tris,edge", [(1, 0.001), (1, 5.0), (3, 2.0)])
+def test_scenes_of_one_to_three_triangles(tris, edge):
+    """The smallest inputs the ABI can carry: one speck, one triangle larger than the view, three of them (every grid plane of an
+    axis is one of <= 9 vertex coordinates: 256 cells share a handful of distinct planes)."""
+    sc = S.make_soup(130, 70, tris, edge, seed=3, samples=1)
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=4)
+    assert_planes(R.render_resident(sc, 0), want, f"{tris} triangle(s), resident layer")
+    ok, r, g, b = R.raytrace_all(1, sc)
+    assert ok
+    assert_planes((r, g, b), want, f"{tris} triangle(s), drop-in")
+
+
 def test_crowded_cells_take_the_flat_list_and_the_in_place_loop():
     """The quantile grid keeps cells sparse (a soup has <= 4 candidates per cell), so crowded cells are made: stacks of identical
     and of slightly shifted triangles.  Cells with 2-14 candidates put their further candidates on the trace kernel's per-wave
