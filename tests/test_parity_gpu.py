@@ -118,6 +118,21 @@ def test_scenes_of_one_to_three_triangles(tris, edge):
     assert_planes((r, g, b), want, f"{tris} triangle(s), drop-in")
 
 
+def test_scene_without_triangles():
+    """No geometry at all (empty vertex / index arrays, empty lists built by the library): black planes from both layers, no error."""
+    sc = S.make_soup(70, 50, 1, 0.01, seed=3, samples=2)
+    sc.vertex = np.zeros((0, 4), np.float32); sc.tri_index = np.zeros((0, 4), np.int32); sc.tri_material = np.zeros(0, np.int32)
+    sc.tri_uv = np.zeros((0, 2), np.float32); sc.tri_normal = np.zeros((0, 4), np.float32)
+    R.build_lists(sc)
+    assert sc.cam_list.size == 0 and sc.grid_list.size == 0
+    want = O.oracle_render(sc, threads=2)
+    assert int(np.max(want[0])) == 0
+    assert_planes(R.render_resident(sc, 0), want, "empty scene, resident layer")
+    ok, r, g, b = R.raytrace_all(1, sc)
+    assert ok
+    assert_planes((r, g, b), want, "empty scene, drop-in")
+
+
 def test_crowded_cells_take_the_flat_list_and_the_in_place_loop():
     """The quantile grid keeps cells sparse (a soup has <= 4 candidates per cell), so crowded cells are made: stacks of identical
     and of slightly shifted triangles.  Cells with 2-14 candidates put their further candidates on the trace kernel's per-wave
