@@ -33,7 +33,9 @@ __device__ __forceinline__ void store_single_sample(const RtDevScene &S, uint32_
 {
     const uint32_t slot = localPixel / RT_TILE_PIXELS, inTile = localPixel % RT_TILE_PIXELS;
     uint16_t *planes = S.tileBuf + (size_t)slot * 3 * RT_TILE_PIXELS + inTile;
-    const float scale = (float)(0xFFFF) / (float)S.sampleCount; // :728 (sampleCount is 1 here)
+    uint32_t samples = S.sampleCount; // :728 (1 here).  Opaque, so that the quotient is made where it is used: hoisted to the top of the
+    asm volatile("" : "+s"(samples)); // logic kernel it lived in a vector register across the state machine and was spilled
+    const float scale = (float)(0xFFFF) / (float)samples;
     planes[0] = (uint16_t)sat_add_u16(0, c.x, scale);
     planes[RT_TILE_PIXELS] = (uint16_t)sat_add_u16(0, c.y, scale);
     planes[2 * RT_TILE_PIXELS] = (uint16_t)sat_add_u16(0, c.z, scale);
@@ -617,7 +619,9 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                     cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
                     cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
                     if (cur_fromCamera) {
-                        res_tri = camera_scan_compact(S, meta.y, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
+                        uint32_t localPixel = meta.y; // (opaque: the list addresses are worked out here, not carried from the prologue)
+                        asm volatile("" : "+v"(localPixel));
+                        res_tri = camera_scan_compact(S, localPixel, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         pc = PC_RAY_RESULT;
                     } else if (laState == 2u && laIndex == head) { // traced ahead of time: the answer is already here
                         res_tri = resolve_hit(S, laKey, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
