@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 #define RT_WF_LOGIC_WAVES 3
 #endif
 #ifndef RT_WF_LOGIC_WAVES_FIRST
-#define RT_WF_LOGIC_WAVES_FIRST 2
+#define RT_WF_LOGIC_WAVES_FIRST 3
 #endif
 #define RT_WF_LIGHTS_LDS 64
 #ifdef RT_DIAG_LOGIC // diagnostic build: where a wave is at which time, round RT_DIAG_LOGIC (no waits added; scripts/diag_logic.py)
@@ -365,12 +365,14 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
         uint32_t rexcl = RT_NONE, laexcl = RT_NONE, a = 0;
 
         if (live) {
-            // Round 0 issues its loads in as few dependent batches as the data allows -- a wave runs one chunk and has one or two
+            // Round 0 issues its loads in as few dependent batches as the data allows -- a wave runs one chunk and has two
             // neighbours on its SIMD, so the chunk lasts as long as its chain of memory round trips (measured: ~8 of them at
             // 2-4 us each before the first shading instruction when every load sat next to its use).  Batch one: the primary hit,
-            // the path's state and the camera ray; batch two: the hit triangle's shading row.  That costs registers: the round-0
-            // instantiation runs at 2 waves per SIMD (213 VGPRs, nothing spilled: 114 -> 100 us), later rounds, whose paths are
-            // in different stages, keep their loads next to the uses and 3 waves (batching them too measured 100 -> 120 us).
+            // the generator and the camera ray; batch two: the hit triangle's shading row.  Later rounds, whose paths are in
+            // different stages, keep their loads next to the uses (batching them too measured 100 -> 120 us).  Both instantiations
+            // fit 3 waves per SIMD without a spilled register (166 / 164 VGPRs) only because nothing that is wanted at the far end
+            // of the state machine is carried across it: addresses, the sample scale, the output slot are made or read again
+            // where they are used (a spill reload in this kernel is a wait for everything in flight).
             uint32_t res_tri = RT_NONE;
             float res_t = 0.f, res_l1 = 0.f, res_l2 = 0.f;
             unsigned long long key = ~0ull;
@@ -386,7 +388,9 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
             }
             float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
             uint64_t rng = W.rng[a];
-            const uint4 meta = W.meta[a];
+            // (round 0 knows the path's flags and its hit triangle; the output slot and the pixel are wanted at the very end only and are
+            // read then, instead of occupying two registers across the state machine)
+            const uint4 meta = FIRST ? make_uint4(0u, 0u, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), res_tri) : W.meta[a];
             V3 out = mk(0.f, 0.f, 0.f); // (round 0: nothing collected yet)
             float4 c0 = qo, c1 = qo, c2 = qo;
             unsigned long long laKey = ~0ull;
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                     cur_bounces = (int)(__float_as_uint(c2.w) >> 1);
                     cur_fromCamera = (int)(__float_as_uint(c2.w) & 1u);
                     if (cur_fromCamera) {
-                        uint32_t localPixel = meta.y; // (opaque: the list addresses are worked out here, not carried from the prologue)
+                        uint32_t localPixel = FIRST ? W.meta[a].y : meta.y; // (opaque: the list addresses are worked out here, not carried from the prologue)
                         asm volatile("" : "+v"(localPixel));
                         res_tri = camera_scan_compact(S, localPixel, cur_o, cur_d, cur_tmin, RT_INF, cur_excl, res_t, res_l1, res_l2);
                         pc = PC_RAY_RESULT;
@@ -651,8 +655,9 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
 
             if (laexcl != 12345u) DG(7);
             if (finished) {
-                if (S.sampleCount == 1u) store_single_sample(S, meta.y, out);
-                else W.sampleOut[meta.x] = pack4(out, 0.f);
+                const uint2 where2 = FIRST ? *reinterpret_cast<const uint2 *>(W.meta + a) : make_uint2(meta.x, meta.y); // {output slot, pixel}
+                if (S.sampleCount == 1u) store_single_sample(S, where2.y, out);
+                else W.sampleOut[where2.x] = pack4(out, 0.f);
             } else {
                 // park the path in HBM until the grid has answered.  The index is made opaque here so that the store addresses are
                 // worked out again (two instructions each) instead of being the prologue's load addresses kept alive across the
@@ -661,8 +666,10 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                 asm volatile("" : "+v"(a));
                 if (rngDirty) W.rng[a] = rng;
                 if (outDirty) W.outc[a] = pack4(out, 0.f);
-                W.meta[a] = make_uint4(meta.x, meta.y, (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | ((attStored ? 1u : 0u) << 9) |
-                                                       (laState << 10) | ((uint32_t)laIndex << 12) | (j << 16), hit_tri);
+                const uint32_t flags = (uint32_t)head | ((uint32_t)tail << 4) | (emitStage << 8) | ((attStored ? 1u : 0u) << 9) | (laState << 10) |
+                                       ((uint32_t)laIndex << 12) | (j << 16);
+                if (FIRST) reinterpret_cast<uint2 *>(W.meta + a)[1] = make_uint2(flags, hit_tri); // (slot and pixel stay as wf_primary_kernel wrote them)
+                else W.meta[a] = make_uint4(meta.x, meta.y, flags, hit_tri);
                 if (laState == 2u && laFetched) W.laKey[a] = laKey;
                 if (emitStage == WS_SHADOW) {
                     W.shP[a] = pack4(P, ndl);
