@@ -837,10 +837,10 @@ __global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const
 #pragma unroll
     for (int i = 0; i < 9; ++i) cut[i] = RT_INF;
     if (active) {
-        W.hitKey[mine] = ~0ull; // no segment of this request has a hit yet
         const float4 ro = W.reqO[in][mine], rd = W.reqD[in][mine];
         o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
         excluded = W.reqX[in][mine].x;
+        W.hitKey[mine] = ~0ull; // no segment of this request has a hit yet (after the loads: a wait for them would wait for this store too)
         // start / end cells (:351-362)
         int cx = 0, cy = 0, cz = 0, ex = 0, ey = 0, ez = 0;
         V3 from = along(o, tmin, d);
