@@ -375,6 +375,10 @@ int rtHipWritePpm(const char *path, cl_uint width, cl_uint height, const cl_usho
 enum { RT_KAT_RANDF = 0, RT_KAT_SPHERE, RT_KAT_PMODF, RT_KAT_TRI, RT_KAT_PLINE, RT_KAT_BOX, RT_KAT_BIND, RT_KAT_POW, RT_KAT_QUOTIENT, RT_KAT_OPS };
 int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint inStride, void *out, cl_uint outStride, const float *table);
 
+/* TEST-ONLY: the content hash RaytraceAll's scene cache compares per input array (rt_api.cpp, hash_chunk), on the host.  Two byte
+ * strings that differ must hash differently for the cache to notice an edit; tests/test_abi.py probes the tail handling. */
+uint64_t rtHipTestHashBytes(const void *bytes, uint64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -461,6 +461,8 @@ int build_lights(rtHipScene *sc, const rtHipSceneDesc *d)
     RtDevScene &D = sc->dev;
     if (d->lightCount >= 65536u) return fail("lightCount %u too large", d->lightCount);
     D.lightCount = d->lightCount;
+    if (d->lightCount && (!d->lightType || !d->lightPos || !d->lightDir || !d->lightCol || !d->lightRadius || !d->lightHalfAtt))
+        return fail("null light array with lightCount %u", d->lightCount); // (the spread below reads two of them before upload() would notice)
     std::vector<float> spread(d->lightCount ? d->lightCount : 1, 0.f);
     for (uint32_t j = 0; j < d->lightCount; ++j) {
         const float *ld = d->lightDir[j].s;
@@ -1183,8 +1185,15 @@ uint64_t hash_chunk(const unsigned char *p, size_t n)
         c = (c ^ w[2]) * 0x9fb21c651e98df25ull; c = (c << 29) | (c >> 35);
         d = (d ^ w[3]) * 0x9fb21c651e98df25ull; d = (d << 29) | (d >> 35);
     }
+    // the tail (< 32 bytes): whole 8-byte words folded one by one, then the last partial word -- each assembled in a zeroed word
+    // of its own, so that no byte is ever ORed over another one's bits
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        a = mix64(a ^ w);
+    }
     uint64_t tail = 0;
-    for (int k = 0; i < n; ++i, ++k) tail |= (uint64_t)p[i] << (8 * (k & 7)), a = (k & 7) == 7 ? mix64(a ^ tail) : a;
+    if (i < n) memcpy(&tail, p + i, n - i);
     return mix64(a ^ mix64(b ^ mix64(c ^ mix64(d ^ tail ^ (uint64_t)n))));
 }
 
@@ -1249,6 +1258,8 @@ std::mutex g_cacheMutex;
 } // namespace
 
 extern "C" {
+
+uint64_t rtHipTestHashBytes(const void *bytes, uint64_t count) { return hash_chunk((const unsigned char *)bytes, (size_t)count); }
 
 void rtHipCacheClear(void)
 {
@@ -1394,6 +1405,7 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
             sc->progress = &g_progress;
             sc->progressBase = 0.999f * (float)g / (float)count;
             sc->progressSpan = 0.999f / (float)count;
+            sc->eventsUsed = 0; // one event pair per call: nobody asks the drop-in layer for kernel times, and a cached scene lives on
             ok = rtHipRenderTiles(sc, nullptr) == 0;
             if (ok && sc->unverified) { // a planned frame runs without the host: follow the batch counter its kernels bump
                 const uint32_t batches = (d.sampleCount + sc->samplesPerBatch - 1) / sc->samplesPerBatch * (uint32_t)sc->groups.size();

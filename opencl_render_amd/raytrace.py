@@ -66,7 +66,7 @@ RESIDENT_SYMBOLS = [
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipDetileStore", "rtHipDeviceAlloc", "rtHipDeviceFree", "rtHipDeviceCopy", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
-    "rtHipDeviceKat",
+    "rtHipDeviceKat", "rtHipTestHashBytes",
     "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
 ]
 
@@ -150,6 +150,8 @@ def lib() -> C.CDLL:
     L.rtHipBuildCameraListDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, vp, f32, u32, u32, vp, vp,
                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
     L.rtHipDeviceKat.argtypes = [C.c_int, C.c_int, u32, vp, u32, vp, u32, vp]
+    L.rtHipTestHashBytes.restype = u64
+    L.rtHipTestHashBytes.argtypes = [vp, u64]
     L.rtHipFree.argtypes = [vp]
     L.rtHipFree.restype = None
     _lib = L

@@ -30,17 +30,20 @@ def max_tiles_per_rank(width: int, height: int, world: int) -> int:
     return (n + world - 1) // world
 
 
-def gather_tiles(local: torch.Tensor, width: int, height: int, rank: int, world: int, group=None) -> Optional[torch.Tensor]:
+def gather_tiles(local: torch.Tensor, width: int, height: int, rank: int, world: int, group=None,
+                 force_collective: bool = False) -> Optional[torch.Tensor]:
     """Gathers the ranks' tile buffers (uint8 tensors of ntiles_r*TILE_BYTES bytes) to rank 0.
 
     Ranks may own one tile fewer than others; every message is padded to max_tiles_per_rank so the collective is a
-    plain equal-size gather.  Returns on rank 0 a [world, max_tiles*TILE_BYTES] uint8 tensor, None elsewhere."""
+    plain equal-size gather.  Returns on rank 0 a [world, max_tiles*TILE_BYTES] uint8 tensor, None elsewhere.
+    A single rank has nothing to gather and gets its own buffer back; `force_collective` issues the collective all the
+    same (tests run the RCCL path on a one-GPU box that way)."""
     cap = max_tiles_per_rank(width, height, world) * TILE_BYTES
     send = local
     if local.numel() != cap:
         send = torch.zeros(cap, dtype=torch.uint8, device=local.device)
         send[: local.numel()] = local
-    if world == 1:
+    if world == 1 and not force_collective:
         return send.view(1, cap)
     if dist.get_backend(group) == "gloo" and send.is_cuda:
         # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
@@ -81,10 +84,11 @@ _ARRAY_FIELDS = ["eye", "eye_to_top_left", "left_to_right", "top_to_bottom", "ve
                  "light_radius", "light_half_att", "cam_start", "cam_end", "cam_list", "box_min", "grid_start", "grid_list"]
 
 
-def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=None) -> Scene:
+def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=None, rebuild_on_root: bool = False) -> Scene:
     """Rank 0 holds the scene (and its lists); every other rank receives a copy.  Arrays travel as byte tensors on
     `device` -- over xGMI with the nccl backend -- instead of every rank rebuilding or re-reading them
-    ('upload once via root then broadcast')."""
+    ('upload once via root then broadcast').  `rebuild_on_root`: rank 0 too returns a scene made from the
+    broadcast tensors instead of the one it was given (tests: the bytes that travelled are the bytes that are used)."""
     head = [None]
     if rank == 0:
         scalars = dict(width=sc.width, height=sc.height, pixel_size_inv=sc.pixel_size_inv, sample_count=sc.sample_count,
@@ -105,9 +109,10 @@ def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=
             t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if nbytes:
             dist.broadcast(t, src=0, group=group)
-        arrays[k] = getattr(sc, k) if rank == 0 else t.cpu().numpy().view(np.dtype(dtype)).reshape(shape).copy()
+        keep = rank == 0 and not rebuild_on_root
+        arrays[k] = getattr(sc, k) if keep else t.cpu().numpy().view(np.dtype(dtype)).reshape(shape).copy()
         del t
-    if rank == 0:
+    if rank == 0 and not rebuild_on_root:
         return sc
     return Scene(**scalars, **arrays)
 

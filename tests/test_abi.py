@@ -116,3 +116,25 @@ def test_without_a_gpu_everything_that_computes_fails(gpu_count):
     assert not ok
     with pytest.raises(RuntimeError, match="no HIP device"):
         R.ResidentScene(sc, 0)
+
+
+def test_cache_hash_sees_every_tail_byte(hip_lib):
+    """The scene cache decides 'unchanged' from content hashes alone: an edit confined to the last bytes of an array must
+    change the hash.  The cases are the ones an ORed tail word missed (light 2's bits a subset of light 0's)."""
+    def h(a):
+        a = np.ascontiguousarray(a)
+        return hip_lib.rtHipTestHashBytes(a.ctypes.data_as(C.c_void_p), a.nbytes)
+    assert h(np.array([1, 2, 0.5], np.float32)) != h(np.array([1, 2, 1.0], np.float32))       # lightRadius, 12-byte tail
+    assert h(np.array([3, 0, 1], np.int32)) != h(np.array([3, 0, 2], np.int32))                   # lightType
+    assert h(np.array([7, 7, 7, 7, 7, 7, 3], np.int32)) != h(np.array([7, 7, 7, 7, 7, 7, 1], np.int32))  # triMaterial, T % 8 == 7
+    rng = np.random.default_rng(5)
+    for n in list(range(1, 100)) + [255, 1000, 4097]:
+        base = rng.integers(0, 256, n, dtype=np.uint8)
+        seen = {h(base)}
+        for i in range(max(0, n - 40), n):  # flip every bit pattern position in the last 40 bytes, one byte at a time
+            for bit in (1, 0x80, 0xff):
+                e = base.copy()
+                e[i] ^= bit
+                v = h(e)
+                assert v not in seen, (n, i, bit)
+        assert h(base[:-1]) != h(base) if n > 1 else True

@@ -598,3 +598,63 @@ def test_planned_frames_with_several_sample_batches(monkeypatch):
         finally:
             rs.close()
     monkeypatch.delenv("RT_WF_STATE_MB")
+
+
+def test_dropin_cache_notices_edits_in_the_last_bytes_of_an_array():
+    """the cache's content hash ORed the tail bytes of an array over each other, so an edit confined to the
+    last words of an array whose size is not a multiple of 32 bytes could go unnoticed and the PREVIOUS picture was returned.
+    Three such edits, each against the oracle's planes of the changed scene: (a) 3 lights, only light 2's type / radius change
+    to values whose bits are a subset of light 0's; (b) an odd triangle count, only the last triangle's third index changes;
+    (c) a triangle count with T % 8 == 5, only the last material id changes."""
+    import copy
+    threads = os.cpu_count() or 1
+    mats = [dict(color=(255, 255, 255), reflection=(0, 0, 0), transparency=(0, 0, 0), bump=(0, 0, 0), luminance=(0, 0, 0)),
+            dict(color=(40, 90, 255), reflection=(0, 0, 0), transparency=(0, 0, 0), bump=(0, 0, 0), luminance=(60, 0, 0))]
+    lights = [dict(type=S.LIGHT_DISTANT, dir=(0.3, -0.8, 0.5), radius=1.0), dict(type=S.LIGHT_SPOT, pos=(0.4, 0.6, 1.0), col=(0.5, 0.5, 0.9), radius=2.0),
+              dict(type=S.LIGHT_SPOT, pos=(-0.5, 0.2, 1.5), col=(0.9, 0.4, 0.3), radius=0.5)]
+    base = S.make_soup(200, 150, 2005, 0.12, seed=61, samples=1, materials=mats, lights=lights, material_ids=np.zeros(2005, np.int32))
+    assert base.triangle_count % 2 == 1 and base.triangle_count % 8 == 5
+    R.build_lists(base)
+
+    def check(sc, what):
+        ok, r, g, b = R.raytrace_all(1, sc)
+        assert ok, R.last_error()
+        assert_planes((r, g, b), O.oracle_render(sc, threads=threads), what)
+        return r, g, b
+
+    first = check(base, "first call")
+    a = copy.copy(base)
+    a.light_radius = base.light_radius.copy(); a.light_radius[2] = 1.0      # bits of 1.0f are those of light 0's radius
+    a.light_type = base.light_type.copy(); a.light_type[2] = S.LIGHT_DISTANT   # 3 = light 0's type (1 is a subset of 3's bits)
+    got = check(a, "(a) only light 2's type and radius changed")
+    assert any(not np.array_equal(x, y) for x, y in zip(got, first))
+    b = copy.copy(a)
+    b.tri_index = a.tri_index.copy()
+    last = b.triangle_count - 1
+    b.tri_index[last, 2] = b.tri_index[0, 2]                               # the last triangle now ends at triangle 0's vertex
+    R.build_lists(b)
+    check(b, "(b) only the last triangle's third index changed")
+    c = copy.copy(b)
+    c.tri_material = b.tri_material.copy(); c.tri_material[last] = 1       # T % 8 == 5: the id sits in a 20-byte tail
+    check(c, "(c) only the last material id changed")
+    R.lib().rtHipCacheClear()
+
+
+def test_more_lights_than_the_logic_kernel_keeps_in_lds():
+    """wf_logic_kernel stages the first 64 lights in LDS and reads the others from global memory; 70 lights of
+    several types put both sides of that split on every hit's light loop (the oracle's planes, bit for bit)."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    lights = []
+    for i in range(70):
+        t = int(rng.choice([S.LIGHT_DISTANT, S.LIGHT_SPOT, S.LIGHT_OMNI, S.LIGHT_AREA, S.LIGHT_PARALLEL]))
+        lights.append(dict(type=t, pos=tuple(rng.uniform(-1, 1, 3) + [0, 0, 1.5]), dir=tuple(rng.uniform(-1, 1, 3)),
+                           col=tuple(rng.uniform(0, 0.08, 3)), radius=float(rng.uniform(0.05, 1)), half_att=float(rng.choice([np.inf, 3.0]))))
+    sc = S.make_soup(96, 64, 1500, 0.2, seed=19, samples=1, lights=lights)
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    got = R.render_resident(sc, 0)
+    assert_planes(got, want, "70 lights")
+    # the lights past the 64th matter: without them the picture differs
+    sc64 = S.make_soup(96, 64, 1500, 0.2, seed=19, samples=1, lights=lights[:64])
+    R.build_lists(sc64)
+    assert not np.array_equal(O.oracle_render(sc64, threads=os.cpu_count() or 1)[0], want[0])
