@@ -375,6 +375,14 @@ int rtHipWritePpm(const char *path, cl_uint width, cl_uint height, const cl_usho
 enum { RT_KAT_RANDF = 0, RT_KAT_SPHERE, RT_KAT_PMODF, RT_KAT_TRI, RT_KAT_PLINE, RT_KAT_BOX, RT_KAT_BIND, RT_KAT_POW, RT_KAT_QUOTIENT, RT_KAT_OPS };
 int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint inStride, void *out, cl_uint outStride, const float *table);
 
+/* TEST / TUNING ONLY.  The library reads no environment variables (a plugin host's environment must not be able to slow frames
+ * down, make them redo themselves or fail); every tuning value and every fault injector of the tests is set here, process-wide,
+ * and applies to scenes built afterwards.  Keys (rt_api.cpp, struct Tuning): "reset" (all defaults), "stage_mb", "extra_factor",
+ * "state_mb", "groups", "lookahead", "seg0".."seg4", "seg_rays0".."seg_rays3", "fast_quotient", "spin_limit", "append_rays",
+ * "slice_rays", "small_slices", "blocking", "batch_plan", "pipeline", "timing", "cache", and the test hooks "plan_rounds",
+ * "plan_grid_tiny", "virtual_devices".  Returns 0, -1 for an unknown key. */
+int rtHipTune(const char *key, double value);
+
 /* TEST-ONLY: the content hash RaytraceAll's scene cache compares per input array (rt_api.cpp, hash_chunk), on the host.  Two byte
  * strings that differ must hash differently for the cache to notice an edit; tests/test_abi.py probes the tail handling. */
 uint64_t rtHipTestHashBytes(const void *bytes, uint64_t count);

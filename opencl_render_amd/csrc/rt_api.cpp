@@ -39,11 +39,11 @@ extern "C" hipError_t rtp_dense_grid(const uint32_t *gridStart, const uint32_t *
                                      uint32_t *pairCount, void *scratch, size_t *scratchBytes, hipStream_t stream);
 
 extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefront *wf, hipStream_t stream);
-extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, uint32_t slicesIn, const RtRoundMode *next, hipStream_t stream);
+extern "C" hipError_t rtw_launch_scatter(const RtWavefront *wf, uint32_t round, uint32_t blocks, const RtRoundMode *mode, hipStream_t stream);
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, const RtRoundMode *mode, hipStream_t stream);
 extern "C" hipError_t rtw_launch_status(const RtWavefront *wf, uint32_t round, hipStream_t stream);
 extern "C" hipError_t rtw_launch_accum(const RtDevScene *scene, const RtWavefront *wf, int first, hipStream_t stream);
-extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, int appendedPlan, hipStream_t stream);
 
 namespace {
 
@@ -65,6 +65,36 @@ int fail(const char *fmt, ...)
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));              \
     } while (0)
+
+// Tuning values and test hooks.  The library reads NO environment variables: a plugin host's environment must not be able to
+// make frames slower, redo themselves or fail.  Everything here is set through rtHipTune() (include/raytrace_hip.h, test / tuning
+// entry point; the Python stub maps RT_* variables of ITS process onto it for the sweep scripts) and applies to scenes built
+// afterwards.
+struct Tuning {
+    uint32_t stageMb = 32;          // size of each of the two pinned staging buffers of an upload
+    uint32_t extraFactor = 6;       // region B of the entry arrays, in units of the path capacity
+    uint64_t stateMb = 0;           // path-state budget per sample batch (0 = 24 GB, never more than a third of free memory); tests force several batches
+    uint32_t groups = 1;            // concurrent tile groups per instance (measured: no gain once rays are cut into segments)
+    uint32_t lookAhead = 1;         // 0: one ray in flight per path
+    uint32_t segLen[5] = { 4096u, 384u, 96u, 64u, 16u }; // aimed-at cell visits per segment for rounds with >= segRays[0] | [1] | [2] | [3] | fewer rays
+    uint32_t segRays[4] = { 700000u, 300000u, 100000u, 30000u };
+    uint32_t fastQuotient = 1;
+    uint32_t spinLimit = 16384;     // a ray makes at most 766 cell visits = 154 walk phases; lowered by the test of the guard's error path
+    uint32_t appendRays = 150000;   // rounds with fewer rays are traced in queue order, unsorted
+    uint32_t sliceRays = 150000;    // rounds with fewer rays use smallSlices queue slices per kind instead of RT_WF_SHARDS
+    uint32_t smallSlices = 16;
+    uint32_t blocking = 0;          // 1: every frame watches its queue (no launch plan)
+    uint32_t planRounds = 0;        // test hook: planned frames issue at most this many rounds, so that the too-short-plan path runs
+    uint32_t planGridTiny = 0;      // test hook: planned trace grids of one workgroup, so that the too-small-grid path runs
+    uint32_t pipeline = RT_HIP_PIPELINE_WAVEFRONT;
+    uint32_t timing = 0;            // 1: where the time of a scene build / a RaytraceAll call goes (stderr)
+    uint32_t virtualDevices = 0;    // test hook: the all-GPUs id deals the tiles over this many instances on the devices that are there
+    uint32_t cache = 1;             // 0: RaytraceAll builds and frees per call, like the reference
+    uint32_t batchPlan = 1;         // 1: the sample batches after a watched frame's first are issued from that batch's launch plan
+};
+Tuning g_tune;
+std::mutex g_tuneMutex;
+Tuning tuning() { std::lock_guard<std::mutex> lock(g_tuneMutex); return g_tune; }
 
 // Device scratch of a scene build: freed when the scope ends, whichever way it ends.
 struct DevScratch {
@@ -92,8 +122,7 @@ struct Stager {
     int init(hipStream_t st)
     {
         stream = st;
-        size = (size_t)32 << 20;
-        if (const char *b = getenv("RT_HIP_STAGE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 4096) size = (size_t)v << 20; }
+        size = (size_t)std::min<uint32_t>(std::max<uint32_t>(tuning().stageMb, 1u), 4096u) << 20;
         for (int i = 0; i < 2; ++i) {
             HIP_OK(hipHostMalloc((void **)&buf[i], size, hipHostMallocDefault));
             HIP_OK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
@@ -182,17 +211,21 @@ struct rtHipScene {
         uint32_t slot0 = 0, slot1 = 0;  // this group's range of the instance's tile slots
         // launch plan (render_wavefront): what the last discovery frame needed
         uint32_t roundsNeeded = 0;
-        uint32_t planEntries[RT_WF_ROUND_LOG] = { 0 }, planEntriesNext[RT_WF_ROUND_LOG] = { 0 };
-        uint32_t planSorted[RT_WF_ROUND_LOG] = { 0 }, planSortedNext[RT_WF_ROUND_LOG] = { 0 }; // != 0: some batch's round went through the counting sort
+        // per round: rays (entries in region A), the longest queue slice, entries in region B -- the maximum over the watched batches
+        // longest = longest queue slice x slices in use (what one slice per kind would hold at most); it and extra depend on the layout the
+        // round had when it was logged: `slices` (the fewest of the batches), `segLen` (the finest)
+        struct RoundPlan { uint32_t rays = 0, longest = 0, extra = 0, slices = RT_WF_SHARDS, segLen = 4096; };
+        uint4 *hostLog = nullptr;       // pinned + mapped: RtWavefront::roundLog, written by the kernels, read by the host after a sync
+        RoundPlan plan[RT_WF_ROUND_LOG], planNext[RT_WF_ROUND_LOG];
+        std::vector<RtRoundMode> modes; // how the rounds of the batch being issued are laid out (modes[r] is decided when logic(r-1) is launched)
+        uint64_t guessRays = 0;         // watched batches: what the next round is assumed to hold
     };
     std::vector<Group> groups;
     hipEvent_t forkEvent = nullptr;
     uint32_t samplesPerBatch = 1;
     uint32_t planRounds = 0;   // rounds a planned frame issues per batch; 0 = no plan yet (the next frame is a discovery frame)
-    bool blocking = false;     // RT_WF_BLOCKING=1: every frame watches the queue (no plan)
-    bool planNoScatter = false; // RT_WF_PLAN_SORT=skip (test hook): planned frames claim every round was appended, so that the sorted-after-all path runs
-    bool planGridTiny = false; // RT_WF_PLAN_GRID=tiny (test hook): planned trace grids of one workgroup, so that the too-small-grid path runs
-    uint32_t planCap = 0;      // RT_WF_PLAN_ROUNDS=n (test hook): planned frames issue at most n rounds, so that the too-short-plan path runs
+    bool blocking = false;     // every frame watches the queue (no plan)
+    Tuning tune;               // the tuning values this scene was built with (rtHipTune)
     bool unverified = false;   // planned frames were issued since the last frame_finish()
     hipStream_t lastStream = nullptr; // where the last frame was issued
     std::atomic<float> *progress = nullptr; // drop-in layer: where finished sample batches are reported (GetProgress, raytrace.c:566-587)
@@ -487,6 +520,7 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     for (auto &G : sc->groups) {
         if (G.hostCount) (void)hipHostFree(G.hostCount);
         if (G.hostStatus) (void)hipHostFree(G.hostStatus);
+        if (G.hostLog) (void)hipHostFree(G.hostLog);
         if (G.stream) { (void)hipStreamSynchronize(G.stream); (void)hipStreamDestroy(G.stream); }
         if (G.done) (void)hipEventDestroy(G.done);
     }
@@ -497,16 +531,16 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     D.sampleCount = sampleCount;
     sc->planRounds = 0; // the next frame watches its queue again
     sc->unverified = false;
+    const Tuning &T = sc->tune;
     const uint32_t nt = D.tileCount;
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, sc->device));
     const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-    // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot; per queue entry (two per path): request,
-    // result, staging + sorted entry
-    uint32_t extraFactor = 6; // region B of the entry arrays, in units of the path capacity: a region-cut ray has up to 9 extra entries
-    if (const char *b = getenv("RT_WF_EXTRA_FACTOR")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) extraFactor = (uint32_t)v; }
-    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * (2 * 40 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 8) + 16;
+    const uint32_t extraFactor = std::min<uint32_t>(std::max<uint32_t>(T.extraFactor, 1u), 16u);
+    // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot, primary hit; per queue entry (two per path and round
+    // parity): path id + answer; per entry (2 + extraFactor per path and parity): the 64-byte entry; per entry: rank, class, sorted position
+    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * 2 * (4 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 4 + 2 + 4) + 16;
     // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
     // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
     uint64_t budget = 24ull << 30;
@@ -514,41 +548,16 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB / 3 < budget) budget = freeB / 3;
     }
-    if (const char *b = getenv("RT_WF_STATE_MB")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) budget = (uint64_t)v << 20; } // tests force several batches
+    if (T.stateMb) budget = T.stateMb << 20;
     uint64_t sb = budget / (perPath * (pix ? pix : 1));
     if (sb < 1) sb = 1;
     if (sb > sampleCount) sb = sampleCount;
     if (sb > 65535) sb = 65535; // the primary kernel's gridDim.y
     sc->samplesPerBatch = (uint32_t)sb;
-    uint32_t groupCount = 1; // RT_WF_GROUPS: concurrent tile groups per instance (measured: no gain once rays are cut into segments)
-    if (const char *b = getenv("RT_WF_GROUPS")) { const unsigned long v = strtoul(b, nullptr, 10); if (v >= 1 && v <= 16) groupCount = (uint32_t)v; }
+    uint32_t groupCount = std::min<uint32_t>(std::max<uint32_t>(T.groups, 1u), 16u);
     if (groupCount > nt) groupCount = nt ? (uint32_t)nt : 1u;
-    uint32_t lookAhead = 1; // RT_WF_LOOKAHEAD=0: one ray in flight per path
-    if (const char *b = getenv("RT_WF_LOOKAHEAD")) lookAhead = (b[0] != '0') ? 1u : 0u;
     const bool multiLight = D.lightCount > 1;
     sc->wfMultiLight = multiLight;
-    // segment lengths by round size (rt_wavefront.hip, wf_setup_kernel); 4096 is longer than any walk = no cutting
-    uint32_t segLen[5] = { 4096u, 384u, 96u, 64u, 16u }, segRays[4] = { 700000u, 300000u, 100000u, 30000u };
-    auto parse_list = [](const char *b, uint32_t *out, int n) {
-        for (int i = 0; i < n && b && *b; ++i) {
-            char *endp = nullptr;
-            const unsigned long v = strtoul(b, &endp, 10);
-            if (endp == b) break;
-            out[i] = (uint32_t)(v ? v : 1);
-            b = (*endp == ',') ? endp + 1 : endp;
-        }
-    };
-    parse_list(getenv("RT_WF_SEG"), segLen, 5);
-    parse_list(getenv("RT_WF_SEG_RAYS"), segRays, 4);
-    // rounds with at least this many rays are cut at region boundaries and traced region by region (rt_wavefront.hip, wf_setup_kernel)
-    uint32_t regionRays = 0xffffffffu; // off by default: measured slower than length order once a cell visit is one fabric request
-    if (const char *b = getenv("RT_WF_REGION_RAYS")) regionRays = (uint32_t)strtoul(b, nullptr, 10);
-    uint32_t fastQuotient = 1u;
-    if (const char *b = getenv("RT_WF_FAST_QUOTIENT")) fastQuotient = (b[0] != '0') ? 1u : 0u;
-    uint32_t spinLimit = 16384u; // a ray makes at most 766 cell visits = 96 walk phases; RT_WF_SPIN_LIMIT lowers the guard to test its error path
-    if (const char *b = getenv("RT_WF_SPIN_LIMIT")) { const unsigned long v = strtoul(b, nullptr, 10); if (v) spinLimit = (uint32_t)v; }
-    uint32_t appendRays = 150000u; // rounds below this are appended to the trace input unsorted (rt_wavefront.hip)
-    if (const char *b = getenv("RT_WF_APPEND_RAYS")) appendRays = (uint32_t)strtoul(b, nullptr, 10);
     if (!sc->forkEvent) HIP_OK(hipEventCreateWithFlags(&sc->forkEvent, hipEventDisableTiming));
     sc->groups.resize(groupCount);
     for (uint32_t g = 0; g < groupCount; ++g) {
@@ -566,13 +575,9 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         RtWavefront &Wf = G.wf;
         Wf.capacity = (uint32_t)cap;
         Wf.shardCap = (uint32_t)shardCap;
-        Wf.lookAhead = lookAhead;
-        for (int i = 0; i < 5; ++i) Wf.segLen[i] = segLen[i];
-        for (int i = 0; i < 4; ++i) Wf.segRays[i] = segRays[i];
-        Wf.appendRays = appendRays;
-        Wf.regionRays = regionRays;
-        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path (RT_WF_QSHARDS slices of shardCap)
-        const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the extra segments of cut rays (a workgroup that finds it full leaves its rays whole)
+        Wf.lookAhead = T.lookAhead ? 1u : 0u;
+        const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path
+        const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the further segments of cut rays (a wave that finds it full leaves its rays whole)
         const uint64_t ecap = qcap + extraCap;
         if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
         Wf.extraCap = (uint32_t)extraCap;
@@ -581,38 +586,31 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
             sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
             sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
             sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<unsigned long long>(cap, &Wf.laKey) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
-            sc->alloc<float4>(qcap, &Wf.reqO[0]) || sc->alloc<float4>(qcap, &Wf.reqO[1]) || sc->alloc<float4>(qcap, &Wf.reqD[0]) ||
-            sc->alloc<float4>(qcap, &Wf.reqD[1]) || sc->alloc<uint2>(qcap, &Wf.reqX[0]) || sc->alloc<uint2>(qcap, &Wf.reqX[1]) ||
-            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
-            sc->alloc<uint4>(ecap * 4, &Wf.stageEnt) || sc->alloc<uint4>(ecap * 4, &Wf.sortedEnt) || sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint8_t>(ecap, &Wf.sortTag) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
-            sc->alloc<uint32_t>(1, &Wf.sortExtra) ||
-            sc->alloc<uint32_t>((uint64_t)3 * RT_WF_QSHARDS, &Wf.counts) ||
-            sc->alloc<uint32_t>(RT_WF_SORT_COPIES * RT_WF_SORT_BINS, &Wf.sortHist) || sc->alloc<uint32_t>(2, &Wf.sortTotal) ||
-            sc->alloc<uint32_t>(RT_WF_ROUND_LOG, &Wf.roundLog))
+            sc->alloc<uint4>(ecap * 4, &Wf.ent[0]) || sc->alloc<uint4>(ecap * 4, &Wf.ent[1]) || sc->alloc<uint32_t>(qcap, &Wf.pathOf[0]) ||
+            sc->alloc<uint32_t>(qcap, &Wf.pathOf[1]) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey[0]) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey[1]) ||
+            sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
+            sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint16_t>(ecap, &Wf.sortTag) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
+            sc->alloc<uint32_t>((uint64_t)3 * RT_WF_CTL_WORDS, &Wf.ctl))
             return -1;
-        HIP_OK(hipMemsetAsync(Wf.roundLog, 0, sizeof(uint32_t) * RT_WF_ROUND_LOG, sc->stream));
-        HIP_OK(hipMemsetAsync(Wf.sortTotal, 0, 2 * sizeof(uint32_t), sc->stream));
-        HIP_OK(hipMemsetAsync(Wf.sortExtra, 0, sizeof(uint32_t), sc->stream));
+        HIP_OK(hipMemsetAsync(Wf.ctl, 0, sizeof(uint32_t) * 3 * RT_WF_CTL_WORDS, sc->stream));
+        HIP_OK(hipHostMalloc((void **)&G.hostLog, sizeof(uint4) * RT_WF_ROUND_LOG, hipHostMallocMapped));
+        memset(G.hostLog, 0, sizeof(uint4) * RT_WF_ROUND_LOG);
+        HIP_OK(hipHostGetDevicePointer((void **)&Wf.roundLog, G.hostLog, 0));
         HIP_OK(hipHostMalloc((void **)&G.hostCount, sizeof(uint32_t) * RT_WF_SHARDS, hipHostMallocDefault));
         HIP_OK(hipHostMalloc((void **)&G.hostStatus, sizeof(uint32_t) * RT_WF_STATUS_WORDS, hipHostMallocMapped));
         memset(G.hostStatus, 0, sizeof(uint32_t) * RT_WF_STATUS_WORDS);
         HIP_OK(hipHostGetDevicePointer((void **)&Wf.hostStatus, G.hostStatus, 0));
-        Wf.spinLimit = spinLimit;
-        Wf.fastQuotient = fastQuotient;
+        Wf.spinLimit = T.spinLimit ? T.spinLimit : 16384u;
+        Wf.fastQuotient = T.fastQuotient ? 1u : 0u;
         // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
-        G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // setup / scatter: two generations of 8 resident workgroups per CU
-        G.traceBlocks = (uint32_t)(ecap / 256); // trace: one workgroup per 256 sorted entries, dispatched in order; surplus groups exit at once
+        G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // scatter: two generations of 8 resident workgroups per CU
+        G.traceBlocks = (uint32_t)(ecap / 256); // trace, worst case: one workgroup per 256 entries; surplus groups exit at once
         // (a whole number of waves per queue slice: wf_logic_kernel keeps a wave in one slice)
         G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
         G.logicBlocks = std::max<uint32_t>(RT_WF_SHARDS / 4, (G.logicBlocks + RT_WF_SHARDS / 4 - 1) / (RT_WF_SHARDS / 4) * (RT_WF_SHARDS / 4));
     }
     HIP_OK(hipStreamSynchronize(sc->stream));
-    if (const char *b = getenv("RT_WF_BLOCKING")) sc->blocking = (b[0] != '0');
-    if (const char *b = getenv("RT_WF_PLAN_ROUNDS")) sc->planCap = (uint32_t)strtoul(b, nullptr, 10);
-    if (const char *b = getenv("RT_WF_PLAN_GRID")) sc->planGridTiny = (strcmp(b, "tiny") == 0);
-    if (const char *b = getenv("RT_WF_PLAN_SORT")) sc->planNoScatter = (strcmp(b, "skip") == 0);
-    const char *env = getenv("RT_HIP_PIPELINE");
-    if (env && env[0] == '0') sc->pipeline = RT_HIP_PIPELINE_MEGAKERNEL;
+    sc->blocking = T.blocking != 0;
     return 0;
 }
 
@@ -640,9 +638,11 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
     if ((uint64_t)d->width * d->height > 0xffffffffull) return fail("image too large");
     HIP_OK(hipSetDevice(sc->device));
     HIP_OK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    sc->tune = tuning();
+    sc->pipeline = sc->tune.pipeline == RT_HIP_PIPELINE_MEGAKERNEL ? RT_HIP_PIPELINE_MEGAKERNEL : RT_HIP_PIPELINE_WAVEFRONT;
     if (sc->stager.init(sc->stream) != 0) return -1;
-    // RT_HIP_TIMING=1: where the time of a scene upload goes (stderr)
-    const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    // Tuning::timing: where the time of a scene upload goes (stderr)
+    const bool timing = sc->tune.timing != 0;
     auto tLast = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
         if (!timing) return;
@@ -672,22 +672,52 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
     return 0;
 }
 
-// One frame through the staged pipeline: per sample batch and tile group -- primary, then rounds of (sort, trace, logic) until
+// How a round with `rays` rays is laid out (RtRoundMode, rt_device.h): big rounds are ordered by predicted walk length and spread
+// their appends over all queue slices, small ones are cut into segments and keep their entries dense.
+#define RT_WF_MAXSEG_HOST 12 // RT_WF_MAXSEG of rt_wavefront.hip: segments a ray is cut into at most
+
+// Entries in region B if a round logged with `extra` further segments at `segFrom` visits per segment were cut at `segTo` instead: a
+// cut c times finer makes at most c segments of one (a coarser one never more).
+uint64_t extra_bound(uint64_t rays, uint64_t extra, uint32_t segFrom, uint32_t segTo)
+{
+    if (segTo >= segFrom) return extra;
+    const uint64_t c = ((uint64_t)segFrom + segTo - 1) / segTo;
+    return std::min<uint64_t>(rays * (RT_WF_MAXSEG_HOST - 1), c * extra + (c - 1) * rays);
+}
+
+RtRoundMode mode_for(const Tuning &T, uint64_t rays, uint32_t slicesBefore)
+{
+    RtRoundMode m;
+    m.ordered = rays >= T.appendRays ? 1u : 0u;
+    m.segLen = rays >= T.segRays[0] ? T.segLen[0] : (rays >= T.segRays[1] ? T.segLen[1] : (rays >= T.segRays[2] ? T.segLen[2] : (rays >= T.segRays[3] ? T.segLen[3] : T.segLen[4])));
+    if (m.segLen < 1u) m.segLen = 1u;
+    uint32_t small = T.smallSlices;
+    if (small < 1u || small > RT_WF_SHARDS || (small & (small - 1u))) small = 16u;
+    m.slices = rays >= T.sliceRays ? (uint32_t)RT_WF_SHARDS : small;
+    if (m.slices > slicesBefore) m.slices = slicesBefore; // a slice holds at most the paths of its shards: slices only ever merge
+    return m;
+}
+
+// One frame through the staged pipeline: per sample batch and tile group -- primary, then rounds of (scatter,) trace, logic until
 // no path is waiting for the grid, then the ordered accumulate.  The round count is data dependent.
 //
-// DISCOVERY frame (the first frame of a scene, or RT_WF_BLOCKING=1): rounds are issued in chunks and the queue length is read
-// back after every chunk (one small pinned copy + stream sync per chunk and group).  It leaves a PLAN behind: the number of
-// rounds the frame needed and the trace-input size of every round (RtWavefront::roundLog).
-// PLANNED frames (every later frame): the plan's rounds are issued back to back with right-sized trace grids and NO host
-// synchronisation -- whatever the caller enqueues behind the frame (the tile gather) follows immediately.  The last kernel of
-// a batch (wf_status_kernel) adds the number of paths still waiting to a mapped host word; frame_finish() looks at it after
-// the caller's own synchronisation.  A non-zero count means the plan was too short for this frame (the frames of a scene are
-// deterministic, so that only happens when something about the frame changed): the frame is rendered again as a discovery
-// frame and the caller is told, so that work enqueued behind the incomplete frame can be redone.
+// WATCHED batch (the first batch of a scene's first frame, or Tuning::blocking): rounds are issued in chunks and the queue length
+// is read back after every chunk (one small pinned copy + stream sync per chunk and group).  It leaves a PLAN behind: the number of
+// rounds the batch needed and, per round, its rays, its longest queue slice and its further segments (RtWavefront::roundLog).
+// PLANNED batches (every later frame, and the further batches of a watched frame): the plan's rounds are issued back to back with
+// the layouts and grid sizes the plan implies and NO host synchronisation -- whatever the caller enqueues behind the frame (the tile
+// gather) follows immediately.  The last kernel of a batch (wf_status_kernel) adds the number of paths still waiting to a mapped
+// host word; frame_finish() looks at it after the caller's own synchronisation.  A non-zero count means the plan was too short for
+// this frame (the frames of a scene are deterministic, so that only happens when something about the frame changed, or when a later
+// sample batch needs more than the first one did): the frame is rendered again, every batch watched, and the caller is told, so
+// that work enqueued behind the incomplete frame can be redone.
+// How a round's entries are laid out (ordered or not, cut how finely, how many queue slices) is decided HERE, before the round exists,
+// from the plan -- or, in a watched batch, from a guess: the layout changes when cells are visited, never what is found.
 // Groups run concurrently on their own streams, forked from and joined to `st`; with stage timing on they run one after the
 // other on `st`, so that a kernel's measured duration is its own.
 int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
 {
+    const Tuning &T = sc->tune;
     auto stage = [&](int which, hipStream_t on, auto &&launch) -> hipError_t {
         if (!sc->stageTiming) return launch();
         if (sc->stageEventsUsed == sc->stageEvents.size()) {
@@ -712,34 +742,57 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
         HIP_OK(hipEventRecord(sc->forkEvent, st));
         for (size_t g = 1; g < sc->groups.size(); ++g) HIP_OK(hipStreamWaitEvent(sc->groups[g].stream, sc->forkEvent, 0));
     }
-    const bool planned = !forceDiscovery && !sc->blocking && sc->planRounds > 0;
-    auto trace_blocks = [&](rtHipScene::Group &G, uint32_t r) -> uint32_t {
+    const bool watchedFrame = forceDiscovery || sc->blocking || sc->planRounds == 0;
+    bool planned = !watchedFrame; // per batch: a watched frame's further batches follow its first batch's plan (Tuning::batchPlan)
+    uint32_t planRounds = sc->planRounds;
+    // the layout of round r: from the plan, or (watched batch) from what the round is assumed to hold
+    auto round_mode = [&](rtHipScene::Group &G, uint32_t r) -> RtRoundMode {
+        if (G.modes.size() <= r) {
+            const uint32_t before = G.modes.empty() ? (uint32_t)RT_WF_SHARDS : G.modes.back().slices;
+            uint64_t rays = G.guessRays;
+            if (planned) rays = r < RT_WF_ROUND_LOG ? G.plan[r].rays : 0;
+            else G.guessRays = std::max<uint64_t>(G.guessRays / 4, 1); // (watched: a round is assumed to hold a quarter of the one before)
+            G.modes.resize(r + 1, mode_for(T, rays, before));
+        }
+        return G.modes[r];
+    };
+    auto trace_blocks = [&](rtHipScene::Group &G, uint32_t r, const RtRoundMode &m) -> uint32_t {
         if (!planned || r >= RT_WF_ROUND_LOG) return G.traceBlocks;
-        // the same frame gave this many entries last time: a tenth more plus a few, never more than the worst case; the kernel
-        // strides if that should still be too few
-        const uint64_t want = sc->planGridTiny ? 1 : ((uint64_t)G.planEntries[r] * 11 / 10 + 255) / 256 + 8;
+        if (T.planGridTiny) return 1;
+        // the same frame gave this many entries last time: a tenth more plus a few, never more than the worst case
+        // (a queue slice and region B are as long as the round's layout makes them; logged under another layout they are bounded:
+        // merging k slices gives at most k times the longest, a cut c times finer at most c segments where there was one)
+        const rtHipScene::Group::RoundPlan &P = G.plan[r];
+        const uint64_t longest = ((uint64_t)P.longest + std::min(m.slices, P.slices) - 1) / std::min(m.slices, P.slices);
+        const uint64_t extra = std::min<uint64_t>(extra_bound(P.rays, P.extra, P.segLen, m.segLen), G.wf.extraCap);
+        uint64_t want;
+        if (m.ordered) want = ((P.rays + extra) * 11 / 10 + 255) / 256 + 8;
+        else {
+            const uint64_t rowsMax = (uint64_t)G.wf.capacity / m.slices / 256;
+            const uint64_t rows = std::min<uint64_t>(rowsMax, (longest * 11 / 10 + 255) / 256 + 1);
+            want = (extra ? (extra * 11 / 10 + 255) / 256 + 2 : 0) + 2ull * m.slices * std::max<uint64_t>(rows, 1);
+        }
         return (uint32_t)std::min<uint64_t>(G.traceBlocks, std::max<uint64_t>(want, 1));
     };
     auto issue_round = [&](rtHipScene::Group &G, hipStream_t on) -> int {
         const uint32_t r = G.rounds;
-        if (r > 0) { // the requests appended by logic(r-1): order them, then walk the grid
-            // a planned round whose entries were appended last time needs no scatter launch (wf_setup_kernel raises RT_WF_ERR_GRID if
-            // the round is big enough to be sorted after all: the frame is then rendered again, watched)
-            const int appendedPlan = (planned && r < RT_WF_ROUND_LOG && G.planEntries[r] && (!G.planSorted[r] || sc->planNoScatter)) ? 1 : 0;
-            HIP_OK(stage(4, on, [&] { return rtw_launch_sort(&G.dev, &G.wf, r, G.queueBlocks, appendedPlan, on); }));
-            HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, r, trace_blocks(G, r), on); }));
+        const RtRoundMode mode = r > 0 ? round_mode(G, r) : RtRoundMode{ 0u, 4096u, (uint32_t)RT_WF_SHARDS };
+        if (r > 0) { // the entries appended by logic(r-1): order them if the round is an ordered one, then walk the grid
+            if (mode.ordered) HIP_OK(stage(4, on, [&] { return rtw_launch_scatter(&G.wf, r, G.queueBlocks, &mode, on); }));
+            HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, r, trace_blocks(G, r, mode), &mode, on); }));
         }
-        HIP_OK(stage(1, on, [&] { return rtw_launch_logic(&G.dev, &G.wf, r, G.logicBlocks, on); }));
+        const RtRoundMode next = round_mode(G, r + 1);
+        HIP_OK(stage(1, on, [&] { return rtw_launch_logic(&G.dev, &G.wf, r, G.logicBlocks, mode.slices, &next, on); }));
         ++G.rounds;
         return 0;
     };
-    // Discovery: rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds
+    // Watched: rounds are issued in chunks without looking at the queue.  A one-bounce scene needs exactly three logic rounds
     // (shade the primary hits | consume shadow + bounce answers, shade the bounce hits | consume their shadow answers) with a
     // trace before the last two, so a chunk is 3 rounds.
     auto issue_chunk = [&](rtHipScene::Group &G, hipStream_t on) -> int {
         for (uint32_t k = 0; k < 3 && G.rounds < RT_WF_MAX_ROUNDS; ++k)
             if (issue_round(G, on) != 0) return -1;
-        HIP_OK(hipMemcpyAsync(G.hostCount, G.wf.counts + (G.rounds % 3) * RT_WF_QSHARDS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, on)); // main slices
+        HIP_OK(hipMemcpyAsync(G.hostCount, G.wf.ctl + (G.rounds % 3) * RT_WF_CTL_WORDS + RT_WF_CTL_COUNTS, sizeof(uint32_t) * RT_WF_SHARDS, hipMemcpyDeviceToHost, on)); // main slices
         return 0;
     };
     auto device_error = [&](rtHipScene::Group &G) -> int {
@@ -751,6 +804,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
         return 0;
     };
     uint64_t rounds = 0;
+    bool anyPlannedBatch = false;
     const uint32_t sampleCount = sc->dev.sampleCount;
     for (uint32_t base = 0; base < sampleCount; base += sc->samplesPerBatch) {
         for (size_t g = 0; g < sc->groups.size(); ++g) {
@@ -759,11 +813,13 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
             G.wf.sampleBase = base;
             G.wf.samplesInBatch = std::min<uint32_t>(sc->samplesPerBatch, sampleCount - base);
             G.rounds = 0;
-            HIP_OK(hipMemsetAsync(G.wf.counts, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_QSHARDS, on));
-            if (!planned) HIP_OK(hipMemsetAsync(G.wf.roundLog, 0, sizeof(uint32_t) * RT_WF_ROUND_LOG, on));
+            G.modes.clear();
+            G.guessRays = (uint64_t)(G.slot1 - G.slot0) * RT_TILE_PIXELS * G.wf.samplesInBatch; // round 1 of a watched batch: as if every pixel were a path
+            HIP_OK(hipMemsetAsync(G.wf.ctl, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_CTL_WORDS, on));
+            if (!planned) memset(G.hostLog, 0, sizeof(uint4) * RT_WF_ROUND_LOG); // (nothing of this group is in flight: the batch before was waited for)
             HIP_OK(stage(0, on, [&] { return rtw_launch_primary(&G.dev, &G.wf, on); }));
             if (planned) {
-                while (G.rounds < sc->planRounds)
+                while (G.rounds < planRounds)
                     if (issue_round(G, on) != 0) return -1;
                 HIP_OK(rtw_launch_status(&G.wf, G.rounds, on));
             } else if (issue_chunk(G, on) != 0) return -1;
@@ -779,44 +835,64 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
                     for (int i = 0; i < RT_WF_SHARDS; ++i) waiting += G.hostCount[i];
                     if (waiting == 0) break;
                     if (G.rounds >= RT_WF_MAX_ROUNDS) return fail("wavefront pipeline: more than %d rounds", RT_WF_MAX_ROUNDS);
+                    G.guessRays = 2 * waiting; // the next round holds at most two rays per waiting path
                     if (issue_chunk(G, on) != 0) return -1;
                 }
-                // the plan for the frames to come: the rounds that had anything to trace (+ the logic round that consumed the last
-                // answers), and every round's trace-input size
-                uint32_t log[RT_WF_ROUND_LOG];
-                HIP_OK(hipMemcpyAsync(log, G.wf.roundLog, sizeof log, hipMemcpyDeviceToHost, on));
-                HIP_OK(hipStreamSynchronize(on));
+                // the plan for the batches and frames to come: the rounds that had anything to trace (+ the logic round that consumed
+                // the last answers), and every round's sizes
+                const uint4 *log = G.hostLog; // (mapped host memory; the stream was synchronised in the loop above)
                 uint32_t needed = 1; // logic(0) always runs
                 for (uint32_t r = 1; r < std::min<uint32_t>(G.rounds, RT_WF_ROUND_LOG); ++r)
-                    if (log[r] & 0x7fffffffu) needed = r + 1;
+                    if (log[r].x) needed = r + 1;
                 if (G.rounds > RT_WF_ROUND_LOG) needed = G.rounds;
                 G.roundsNeeded = std::max(G.roundsNeeded, needed);
-                for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) { // (bit 31 of a logged size: the round's entries were appended, not sorted)
-                    G.planEntriesNext[r] = std::max(G.planEntriesNext[r], log[r] & 0x7fffffffu);
-                    if ((log[r] & 0x7fffffffu) && !(log[r] >> 31)) G.planSortedNext[r] = 1u;
+                for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) {
+                    // the maximum over the watched batches, in terms of the finest layout any of them had
+                    rtHipScene::Group::RoundPlan &N = G.planNext[r];
+                    const RtRoundMode m = r < G.modes.size() ? G.modes[r] : RtRoundMode{ 0u, 4096u, (uint32_t)RT_WF_SHARDS };
+                    const uint32_t seg = std::min(N.segLen, m.segLen);
+                    N.extra = (uint32_t)std::min<uint64_t>(0xffffffffu, std::max(extra_bound(N.rays, N.extra, N.segLen, seg), extra_bound(log[r].x, log[r].z, m.segLen, seg)));
+                    N.segLen = seg;
+                    N.rays = std::max(N.rays, log[r].x);
+                    N.longest = std::max(N.longest, log[r].y * m.slices);
+                    N.slices = std::min(N.slices, m.slices);
                 }
-            }
+            } else anyPlannedBatch = true;
             rounds = std::max<uint64_t>(rounds, G.rounds);
             if (sampleCount > 1) // a one-sample frame's pixels were written by the kernels that finished them
                 HIP_OK(stage(3, on, [&] { return rtw_launch_accum(&G.dev, &G.wf, base == 0 ? 1 : 0, on); }));
         }
-        // a watched frame knows here that this batch's rounds are over: tell whoever polls GetProgress (raytrace.c:566-587)
+        // a watched batch knows here that its rounds are over: tell whoever polls GetProgress (raytrace.c:566-587)
         if (!planned && sc->progress)
             sc->progress->store(sc->progressBase + sc->progressSpan * (float)std::min<uint64_t>(sampleCount, (uint64_t)base + sc->samplesPerBatch) / (float)sampleCount,
                                 std::memory_order_relaxed);
+        // A watched frame's further batches: the same pixels with other sample ids -- statistically the same rounds.  They are issued from
+        // the plan the batches so far left (a fifth more than the largest of them saw, see trace_blocks) and verified like any planned
+        // frame; should one of them need more, frame_finish renders the whole frame again, every batch watched.
+        if (!planned && !forceDiscovery && !sc->blocking && T.batchPlan && base + sc->samplesPerBatch < sampleCount) {
+            uint32_t need = 1;
+            for (auto &G : sc->groups) {
+                need = std::max(need, G.roundsNeeded);
+                for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) {
+                    G.plan[r] = G.planNext[r];
+                    G.plan[r].rays += G.plan[r].rays / 10; G.plan[r].longest += G.plan[r].longest / 10 + 8 * G.plan[r].slices; G.plan[r].extra += G.plan[r].extra / 10;
+                }
+            }
+            planRounds = need + 1; // (one spare round: a later batch's deepest path may go one bounce further)
+            planned = true;
+        }
     }
-    if (!planned) { // adopt what this frame needed (the maximum over its batches and groups)
+    if (watchedFrame) { // adopt what this frame's watched batches needed (the maximum over batches and groups)
         uint32_t need = 1;
         for (auto &G : sc->groups) {
             need = std::max(need, G.roundsNeeded);
-            memcpy(G.planEntries, G.planEntriesNext, sizeof G.planEntries);
-            memset(G.planEntriesNext, 0, sizeof G.planEntriesNext);
-            memcpy(G.planSorted, G.planSortedNext, sizeof G.planSorted);
-            memset(G.planSortedNext, 0, sizeof G.planSortedNext);
+            for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) { G.plan[r] = G.planNext[r]; G.planNext[r] = rtHipScene::Group::RoundPlan(); }
             G.roundsNeeded = 0;
         }
-        sc->planRounds = sc->planCap ? std::min(need, sc->planCap) : need;
-    } else sc->unverified = true;
+        if (anyPlannedBatch && sampleCount > sc->samplesPerBatch) need += 1; // (the spare round of the further batches, kept for the frames to come)
+        sc->planRounds = T.planRounds ? std::min(need, T.planRounds) : need;
+    }
+    if (anyPlannedBatch) sc->unverified = true;
     if (!serial)
         for (size_t g = 1; g < sc->groups.size(); ++g) {
             HIP_OK(hipEventRecord(sc->groups[g].done, sc->groups[g].stream));
@@ -849,7 +925,18 @@ int frame_finish(rtHipScene *sc, hipStream_t st, int *redone)
         waiting += G.hostStatus[RT_WF_STATUS_WAITING];
         G.hostStatus[RT_WF_STATUS_WAITING] = 0u;
     }
-    if (waiting == 0) return 0;
+    if (waiting == 0) {
+        // a complete planned frame of one batch logged its rounds under the layouts the plan implies: the plan's sizes become exact
+        // (they were bounds where the watched frame had guessed another layout)
+        if (sc->dev.sampleCount <= sc->samplesPerBatch)
+            for (auto &G : sc->groups)
+                for (uint32_t r = 1; r < std::min<uint32_t>((uint32_t)G.modes.size(), std::min<uint32_t>(G.rounds, RT_WF_ROUND_LOG)); ++r) {
+                    const uint4 l = G.hostLog[r];
+                    G.plan[r].rays = l.x; G.plan[r].longest = l.y * G.modes[r].slices; G.plan[r].extra = l.z;
+                    G.plan[r].slices = G.modes[r].slices; G.plan[r].segLen = G.modes[r].segLen;
+                }
+        return 0;
+    }
     if (redone) *redone = 1;
     if (render_wavefront(sc, st, true) != 0) return -1;
     HIP_OK(hipStreamSynchronize(st));
@@ -896,6 +983,7 @@ void rtHipSceneDestroy(rtHipScene *sc)
     for (auto &G : sc->groups) {
         if (G.hostCount) (void)hipHostFree(G.hostCount);
         if (G.hostStatus) (void)hipHostFree(G.hostStatus);
+        if (G.hostLog) (void)hipHostFree(G.hostLog);
         if (G.stream) { (void)hipStreamSynchronize(G.stream); (void)hipStreamDestroy(G.stream); }
         if (G.done) (void)hipEventDestroy(G.done);
     }
@@ -1259,6 +1347,28 @@ std::mutex g_cacheMutex;
 
 extern "C" {
 
+int rtHipTune(const char *key, double value)
+{
+    if (!key) return fail("rtHipTune: null key");
+    std::lock_guard<std::mutex> lock(g_tuneMutex);
+    Tuning &T = g_tune;
+    const std::string k = key;
+    const uint32_t u = value < 0 ? 0u : (value > 4294967295.0 ? 0xffffffffu : (uint32_t)value);
+    if (k == "reset") { T = Tuning(); return 0; }
+    struct { const char *name; uint32_t *field; } table[] = {
+        { "stage_mb", &T.stageMb }, { "extra_factor", &T.extraFactor }, { "groups", &T.groups }, { "lookahead", &T.lookAhead },
+        { "seg0", &T.segLen[0] }, { "seg1", &T.segLen[1] }, { "seg2", &T.segLen[2] }, { "seg3", &T.segLen[3] }, { "seg4", &T.segLen[4] },
+        { "seg_rays0", &T.segRays[0] }, { "seg_rays1", &T.segRays[1] }, { "seg_rays2", &T.segRays[2] }, { "seg_rays3", &T.segRays[3] },
+        { "fast_quotient", &T.fastQuotient }, { "spin_limit", &T.spinLimit }, { "append_rays", &T.appendRays }, { "slice_rays", &T.sliceRays },
+        { "small_slices", &T.smallSlices }, { "blocking", &T.blocking }, { "plan_rounds", &T.planRounds }, { "plan_grid_tiny", &T.planGridTiny },
+        { "pipeline", &T.pipeline }, { "timing", &T.timing }, { "virtual_devices", &T.virtualDevices }, { "cache", &T.cache }, { "batch_plan", &T.batchPlan },
+    };
+    if (k == "state_mb") { T.stateMb = (uint64_t)(value < 0 ? 0 : value); return 0; }
+    for (auto &e : table)
+        if (k == e.name) { *e.field = u; return 0; }
+    return fail("rtHipTune: unknown key '%s'", key);
+}
+
 uint64_t rtHipTestHashBytes(const void *bytes, uint64_t count) { return hash_chunk((const unsigned char *)bytes, (size_t)count); }
 
 void rtHipCacheClear(void)
@@ -1296,8 +1406,8 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     // "All GPUs": one scene per device with the tiles dealt round-robin, one host thread per device while the scenes are built
     // and the first frame watches its ray queue.  RT_HIP_VIRTUAL_DEVICES=k (test hook): the all-GPUs id deals the tiles over k
     // instances that share the real devices, so the path runs on a one-GPU box.
-    int virt = 0;
-    if (const char *b = getenv("RT_HIP_VIRTUAL_DEVICES")) virt = atoi(b);
+    const Tuning tune = tuning();
+    const int virt = (int)tune.virtualDevices;
     const bool all = (n > 1 && computationType == (cl_uint)n + 1);
     const bool allVirtual = n > 0 && virt > 1 && computationType == (cl_uint)n + 1;
     if (n <= 0 || (!all && !allVirtual && computationType > (cl_uint)n)) {
@@ -1355,13 +1465,12 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
         };
         hash_inputs(jobs, h);
     }
-    const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    const bool timing = tune.timing != 0;
     const auto tHash = std::chrono::steady_clock::now();
 
     std::lock_guard<std::mutex> lock(g_cacheMutex);
     SceneCache &C = g_cache;
-    bool useCache = true;
-    if (const char *b = getenv("RT_HIP_CACHE")) useCache = (b[0] != '0');
+    const bool useCache = tune.cache != 0;
     const bool sameSet = C.valid && C.first == first && C.count == count && C.devices == n && C.width == d.width && C.height == d.height &&
                          (int)C.scenes.size() == count;
     const bool reuse = useCache && sameSet && C.hash[0] == h[0] && C.hash[1] == h[1] && C.hash[2] == h[2];

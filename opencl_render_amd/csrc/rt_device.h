@@ -98,20 +98,18 @@ struct RtDevScene {
 
 // ---- wavefront pipeline buffers (rt_wavefront.hip) -------------------------------------------------------------------
 // A "path" is one sample of one pixel whose primary ray hit something; it gets a dense id `a` (allocated by the
-// primary stage) and lives in HBM between stages as structure-of-arrays state.  Rays that need the grid are appended
-// to a request queue.
-//   round r:   logic(r)   reads  req[r&1][q].path + res[q]  for the entries of counts[r%3]   -> appends to req[(r+1)&1], counts[(r+1)%3]
-//              sort(r+1)  turns the new requests into self-contained entries, longest predicted walk first
-//              trace(r+1) walks the grid for every entry                                      -> writes res[q]
+// primary stage) and lives in HBM between stages as structure-of-arrays state.  A ray that needs the grid becomes a
+// self-contained 64-byte TRACE ENTRY, written by the kernel that spawns it.
+//   round r:   logic(r)   reads  pathOf[r&1][q] + hitKey[r&1][q] (+ the entry's ray) for the entries of counts[r%3]
+//                         -> appends the entries of round r+1 to ent[(r+1)&1], counts[(r+1)%3], and -- for a round that will be
+//                            ordered -- counts them into hist[(r+1)%3]
+//              scatter(r+1)  (ordered rounds only) turns ranks into positions, longest predicted walk first
+//              trace(r+1) walks the grid for every entry                                      -> atomicMin on hitKey[(r+1)&1][q]
 #define RT_WF_MAX_ROUNDS 100000
 #define RT_WF_SHARDS 256      // paths are born into one of this many shards (primary workgroup % RT_WF_SHARDS)
-#define RT_WF_QSHARDS (2 * RT_WF_SHARDS) // queue slices: [0,SHARDS) main requests (one per waiting path), [SHARDS,2*SHARDS) look-ahead requests
-#define RT_WF_SORT_BINS 64    // walk-length classes of the sorted trace input (wf_setup_kernel), 0 = longest
-#define RT_WF_SORT_COPIES 4   // independent histograms (workgroup % copies) to spread the atomics
-#define RT_WF_ORDER_LENGTH 0u
-#define RT_WF_ORDER_APPENDED 1u
-#define RT_WF_ORDER_REGION 2u
-#define RT_WF_REGION_SHIFT 6  // a region is 64 x 64 x 64 cells: 4 x 4 x 4 = 64 regions = RT_WF_SORT_BINS
+#define RT_WF_QSHARDS (2 * RT_WF_SHARDS) // queue slices: [0,SHARDS) main entries (one per waiting path), [SHARDS,2*SHARDS) look-ahead entries
+#define RT_WF_SORT_BINS 64    // walk-length classes of an ordered trace input, 0 = longest
+#define RT_WF_SORT_COPIES 32  // independent histograms (wave % copies): a hot class takes a few thousand returned atomics per round, ~90 per us and address
 // host-visible status words of a tile group (RtWavefront::hostStatus)
 #define RT_WF_STATUS_ERROR 0  // RT_WF_ERR_* bits, sticky until the host clears them
 #define RT_WF_STATUS_WAITING 1 // paths still waiting for the grid when the issued rounds of a batch were over, summed over the batches since the
@@ -120,28 +118,44 @@ struct RtDevScene {
 #define RT_WF_STATUS_WORDS 16
 #define RT_PAIR_MANY 15u            // a first pair record's count field saturates here (rt_device.h, pairRec)
 #define RT_PAIR_LIMIT (1u << 28)    // pair indices must fit the record's rest field and the trace kernel's 29-bit key field
-#define RT_WF_ROUND_LOG 64     // rounds of a batch whose trace-input size is logged for the launch plan (RtWavefront::roundLog)
+#define RT_WF_ROUND_LOG 64     // rounds of a batch that are logged for the launch plan (RtWavefront::roundLog)
 #define RT_WF_ERR_SPIN 1u     // wf_trace_kernel's walk guard tripped: rays were abandoned, the frame is invalid
 #define RT_WF_ERR_GRID 2u     // a planned frame's trace grid was smaller than the round's entries: entries were not traced; the host renders
                               // the frame again with the worst-case grid (rt_api.cpp, frame_finish)
+// per-round control words, three sets used in turn like the queue lengths (round r uses set r % 3): logic(r-1) fills set r,
+// scatter(r) and trace(r) read it, logic(r) zeroes set (r + 2) % 3 for logic(r+1)
+#define RT_WF_CTL_COUNTS 0                                   // [RT_WF_QSHARDS] queue lengths
+#define RT_WF_CTL_HIST RT_WF_QSHARDS                         // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of an ordered round
+#define RT_WF_CTL_EXTRA (RT_WF_CTL_HIST + RT_WF_SORT_COPIES * RT_WF_SORT_BINS) // entries in region B
+#define RT_WF_CTL_TOTAL (RT_WF_CTL_EXTRA + 1)                // ordered round: entries at the front of sortedIdx (written by wf_scatter_kernel)
+#define RT_WF_CTL_WORDS (RT_WF_CTL_TOTAL + 3)                // (multiple of 4)
+
+// How a round's entries are laid out and handed to the trace kernel.  Decided by the HOST before the round exists (from the launch
+// plan the same frame left behind, or from a guess in a watched frame) and passed to the kernels as an argument: a wrong guess
+// costs time, never correctness.
+struct RtRoundMode {
+    uint32_t ordered;   // 1: counting sort by predicted walk length (logic counts, wf_scatter_kernel places); 0: traced in queue order
+    uint32_t segLen;    // aimed-at cell visits per segment (>= 4096: rays are never cut)
+    uint32_t slices;    // queue slices in use per kind (power of two <= RT_WF_SHARDS, never more than the round before): a big round
+                        // spreads its appends over 256 counters, a small one keeps its entries in a few dense stretches
+};
+
 struct RtWavefront {
     uint32_t capacity;       // paths that fit (pixels of this instance's tiles x samplesInBatch)
     uint32_t sampleBase;     // samples sampleBase+1 .. sampleBase+samplesInBatch are in flight (1-based ids, raytrace.c:612-653)
     uint32_t samplesInBatch;
     uint32_t lookAhead;      // 1: a path traces its next ring entry while the current hit's shadow ray is in flight
-    uint32_t fastQuotient;   // 1: waves whose rays all have tame exponents skip the scaling / fix-up instructions of the quotients (RT_WF_FAST_QUOTIENT=0 turns it off)
-    uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (RT_WF_SPIN_LIMIT, default 16384)
+    uint32_t fastQuotient;   // 1: waves whose rays all have tame exponents skip the scaling / fix-up instructions of the quotients
+    uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (default 16384)
     uint32_t *hostStatus;    // pinned HOST words mapped into the device (RT_WF_STATUS_*): written by kernels, read by the host after a sync
-    uint32_t *roundLog;      // [RT_WF_ROUND_LOG] entries (all segments) the trace kernel of round r found, for sizing later frames' launches
-    uint32_t segLen[5];      // aimed-at cell visits per segment for rounds with >= segRays[0] | >= segRays[1] | >= segRays[2] | >= segRays[3] | fewer rays
-    uint32_t segRays[4];     // (RT_WF_SEG="a,b,c,d,e", RT_WF_SEG_RAYS="a,b,c,d"; defaults 4096,384,96,64,16 and 700000,300000,100000,30000)
+    uint4 *roundLog;         // [RT_WF_ROUND_LOG] per round: x rays (entries in region A), y longest queue slice, z entries in region B
     // per-path state, indexed by path id
     unsigned long long *rng; // generator state (raytrace_opencl.c:474-481), already moved past the current hit's light draws
     unsigned long long *rngL; // lightCount > 1 only: where the current hit's NEXT light set-up draws from
     uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel  w: hit triangle
                              // z: head | tail<<4 | stage<<8 | attenuation stored<<9 | look-ahead state<<10 | look-ahead ring index<<12 | light<<16
     unsigned long long *laKey; // answer (hitKey) of the path's look-ahead ray while it waits to be consumed
-    uint32_t *laSlot;        // queue index of the look-ahead request issued last round
+    uint32_t *laSlot;        // queue index of the look-ahead entry issued last round
     float4 *outc;            // accumulated colour xyz
     float4 *ring;            // [capacity][12][3] the pixel's ray queue (:459-468): o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera;
                              // slot `head` is the ray in flight
@@ -149,35 +163,27 @@ struct RtWavefront {
     float4 *shP;             // P.xyz = (1-out)*weight*(1-transparency)*texture, the factors of :649-651 in the reference's order; w: N.L of this light
     float4 *shFace;          // xyz: the face[] entry that :647 will select (the other one is dead); w: 1 if front facing
     float4 *shAtt;           // shadow attenuation so far (only once a transparent occluder was met, :616-625)
-    float4 *shN;             // lightCount > 1 only: shading normal for the next light's set-up (the hit point rides in the request)
-    // ray requests / results.  Queue slice s holds entries [s*shardCap, s*shardCap + counts[s]); a path born into shard s appends
-    // its main requests to slice s and its look-ahead requests to slice RT_WF_SHARDS+s, so appends hit 512 different counters (a
-    // single address sustains only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shard.
-    float4 *reqO[2], *reqD[2]; // o.xyz,tmin | d.xyz,tmax
-    uint2 *reqX[2];            // excluded triangle, path id
+    float4 *shN;             // lightCount > 1 only: shading normal for the next light's set-up (the hit point rides in the entry)
+    // Trace entries, 64 bytes: {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz, rank in wave | segment << 24} -- the ray
+    // and its DDA start state (start / end cell, the three crossing parameters), computed ONCE by the kernel that spawns the ray.
+    // Queue slice s of a round with `slices` slices per kind holds entries [s*sliceCap, s*sliceCap + counts[s]) with sliceCap =
+    // capacity / slices for the main entries and the same range + capacity for the look-ahead entries (counts[RT_WF_SHARDS + s]);
+    // a path born into shard b appends to slice b % slices, so appends hit up to 512 different counters (a single address sustains
+    // only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shards.
+    // A long ray of a round with few rays becomes several entries (SEGMENTS, rt_wavefront.hip): segment 0 sits at the ray's queue
+    // index (region A, [0, 2*capacity)), further segments are packed into region B ([2*capacity, 2*capacity + extraCap)).
+    uint4 *ent[2];             // [2*capacity + extraCap][4], by round parity
+    uint32_t *pathOf[2];       // [2*capacity] path id of queue entry q, by round parity
+    unsigned long long *hitKey[2]; // [2*capacity] per ray: segment << 32 | pair index of the hit in the lowest segment that has one; all ones = no hit
     uint4 *res;                // round 0 only: the primary hit of the path -- triangle, t, l1, l2 (float bits)
-    unsigned long long *hitKey; // per request: segment << 32 | pair index of the hit in the lowest segment that has one; all ones = no hit
-    uint32_t shardCap;         // entries per queue slice = paths per shard (multiple of 256)
-    uint32_t *counts;          // [3][RT_WF_QSHARDS] queue lengths; round r reads [r%3], appends to [(r+1)%3]; zeroed in-stream by the logic kernel
-    // Length-sorted trace input (wf_setup_kernel / wf_scatter_kernel): a round's requests become self-contained 64-byte entries
-    // {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz,-} (DDA start state computed once), keyed by the PREDICTED
-    // number of cell visits (exact for rays that hit nothing) and counting-sorted longest first, so that a wave holds rays of
-    // similar length and the longest walks of the round start first.
-    // A long ray becomes several entries (SEGMENTS, rt_wavefront.hip): segment 0 sits at its request's queue index (region A,
-    // [0, 2*capacity)), further segments are packed into region B ([2*capacity, 2*capacity + extraCap)).
-    uint4 *stageEnt;           // [2*capacity + extraCap][4] entries, {.., cell | (bin | copy<<6)<<24, ..} .. {.., rank in workgroup | segment<<24}
-    uint4 *sortedEnt;          // [2*capacity + extraCap][4] the entries of an APPENDED round (small rounds skip the sort), same layout
-    uint32_t *sortedIdx;       // [2*capacity + extraCap] a SORTED round: index into stageEnt of the entry at each sorted position
+    uint32_t shardCap;         // paths per shard (multiple of 256); capacity = RT_WF_SHARDS * shardCap
+    uint32_t *ctl;             // [3][RT_WF_CTL_WORDS] per-round control words (RT_WF_CTL_*), zeroed in-stream by the logic kernel
+    // An ORDERED round: entries keyed by the PREDICTED number of cell visits (exact for rays that hit nothing), counting-sorted
+    // longest first, so that a wave holds rays of similar length and the longest walks of the round start first.
+    uint32_t *sortedIdx;       // [2*capacity + extraCap] index into ent of the entry at each sorted position
     uint32_t *sortRank;        // [2*capacity + extraCap] rank of the entry inside its (bin, copy) class; 0xffffffff = an unused reservation
-    uint8_t *sortTag;          // [2*capacity + extraCap] the class: bin | copy << 6 (what wf_scatter_kernel needs of an entry, 5 bytes instead of a 64-byte line)
-    uint32_t *sortExtra;       // [1] entries in region B this round
+    uint16_t *sortTag;         // [2*capacity + extraCap] the class: bin | copy << 6 (what wf_scatter_kernel needs of an entry, 6 bytes instead of a 64-byte line)
     uint32_t extraCap;         // capacity of region B (multiple of 256)
-    uint32_t *sortHist;        // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of the current round
-    uint32_t *sortTotal;       // [2] entries at the front of the sorted array | how the round was ordered: 0 by walk length, 1 appended (region B
-                               // holds entries too), 2 by grid region (RT_WF_ORDER_*)
-    uint32_t appendRays;       // rounds with fewer rays than this skip the counting sort (RT_WF_APPEND_RAYS, default 150000)
-    uint32_t regionRays;       // rounds with at least this many rays are cut at REGION boundaries and sorted by region (RT_WF_REGION_RAYS;
-                               // 0xffffffff = never): see wf_setup_kernel
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

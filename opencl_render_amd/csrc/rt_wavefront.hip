@@ -8,9 +8,9 @@
 //               Hits become PATHS: dense id from a wave-aggregated atomic, state written to HBM (rt_device.h).
 //   wf_logic    one thread per waiting path: resumes the per-sample state machine of raytrace_opencl.c:532-724 where it
 //               stopped, runs it until the next grid ray (shadow ray :611, or a queued ray :530) and appends that ray
-//               to the next round's queue; paths with an empty ring retire their colour.
-//   wf_setup / wf_scatter   turn the round's requests into self-contained entries (DDA start state), cut long rays of a
-//               small round into exact segments, and order the entries of a big round by predicted walk length.
+//               to the next round's queue as a self-contained TRACE ENTRY (the ray + its DDA start state; a long ray of
+//               a small round is cut into exact segments); paths with an empty ring retire their colour.
+//   wf_scatter  big rounds only: orders the entries by predicted walk length (the logic kernel counted the classes).
 //   wf_trace    one entry per lane: walks the non-uniform grid (:324-401) in blind phases, tests the occupied cells it
 //               passed wave-cooperatively; a hit is published as (segment, pair) in hitKey and resolved by wf_logic.
 //   wf_accum    frames with several samples: per pixel, samples in order, truncated saturating u16 accumulate into the
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
     // workgroups are dealt to the shards round-robin: concurrently running groups append to different counters
     const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) % RT_WF_SHARDS;
     // the path id doubles as the index of its round-0 queue entry: the primary hit plays the answered request
-    const uint32_t a = shard * W.shardCap + wave_append(&W.counts[shard], born);
+    const uint32_t a = shard * W.shardCap + wave_append(&W.ctl[RT_WF_CTL_COUNTS + shard], born);
     if (born) {
         W.rng[a] = rng;
         W.meta[a] = make_uint4(outSlot, localPixel, 0u | (1u << 4) | ((uint32_t)WS_RAY << 8), hit_tri);
@@ -260,6 +260,118 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
         W.ring[(size_t)a * (RT_RING * 3) + 1] = pack4(dir, __uint_as_float(RT_NONE));
         W.res[a] = make_uint4(hit_tri, __float_as_uint(hit_t), __float_as_uint(hit_l1), __float_as_uint(hit_l2));
     }
+}
+
+// ---- trace entries: the DDA start state of a ray, and exact segments ------------------------------------------------
+// A round lasts as long as its longest dependent chain: a ray that crosses the whole grid makes 766 cell visits one after
+// the other, and measured round times are ~0.4 ms + 0.32 ms per million rays -- the constant is that chain.  The walk is a
+// 3-way merge: per axis, the parameters T_a(i) = (plane_a[i] - o_a) / d_a at which the ray crosses successive planes form a
+// non-decreasing sequence (the same rounded quotients the reference computes, :383-385), and every step takes the smallest
+// head (:387-398).  So the state of the walk after all crossings with T <= tau is, per axis, simply the NUMBER of such
+// crossings -- it can be computed without walking (a plane search plus two exact divides per axis), for any tau.  A long
+// ray is therefore cut into up to RT_WF_MAXSEG SEGMENTS at parameters tau_k: segment k starts in the state at tau_k and ends
+// when it has visited the start cell of segment k+1 (the existing end-cell rule, :380).  Segments are traced as independent
+// entries; the ray's answer is the hit of its lowest segment that has one (atomicMin on hitKey), exactly the first cell
+// with a hit in path order.  Segments after a hit are wasted work; the chain per entry is ~8x shorter.
+//
+// The kernel that spawns a ray (wf_logic_kernel) writes its entries itself: the DDA start state is computed once, there,
+// where the ray is in registers -- a separate set-up kernel between the logic and the trace kernel cost a launch, a second
+// round trip of every request through HBM and 30-50 us per round of a frame whose rounds are 60-600 us (round 2: 49 + 29 us
+// of a 0.98 ms frame, a quarter of what one of eight ranks does per frame).  An ORDERED round's entries are keyed by predicted
+// cell visits and counted into RT_WF_SORT_BINS classes on the way (per wave in LDS, one global atomic instruction per wave);
+// wf_scatter_kernel turns ranks into positions, longest class first.  Only the ORDER and GROUPING in which cells are visited
+// changes.  Cutting costs work (every entry has a start-up and a test batch of its own, segments behind a hit are wasted), so
+// the aimed-at cell visits per segment depend on how many rays the round has (RtRoundMode::segLen, chosen by the host from
+// the launch plan): a round that fills the GPU several times over is bound by its total work and is not cut at all (cutting
+// at 384/256/192/128 visits measured 1-13 % slower), a round with few rays is cut finely enough to occupy every SIMD.
+#ifndef RT_WF_MAXSEG
+#define RT_WF_MAXSEG 12
+#endif
+struct DdaState { uint32_t cell; float dx, dy, dz; };
+
+// One axis of the state at parameter tau: c0 = cell coordinate of the walk's start, returns the coordinate after all
+// crossings with T <= tau and, in `head`, the parameter of the next crossing.  `limit` = crossings that stay inside the grid.
+__device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t c0, float oa, float da, float tau, float &head)
+{
+    const bool pos = (0.f <= da);
+    const int limit = pos ? (int)(RT_GRID_DIV - 1 - c0) : (int)c0; // the crossing after these leaves the grid (tau is before it)
+    // guess from the position (the plane search of GetBoxAddress), then settle it with the exact quotients
+    const float p = oa + tau * da;
+    int g = 0;
+#pragma unroll
+    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2)
+        if (planes[g + div] < p) g += div;
+    int m = pos ? g - (int)c0 : (int)c0 - g;
+    m = m < 0 ? 0 : (m > limit ? limit : m);
+    // crossing number k (1-based) is plane c0+k going up, c0-k+1 going down
+    while (m >= 1 && !((planes[pos ? (int)c0 + m : (int)c0 - m + 1] - oa) / da <= tau)) --m;
+    float next = (planes[pos ? (int)c0 + m + 1 : (int)c0 - m] - oa) / da;
+    while (m < limit && next <= tau) {
+        ++m;
+        next = (planes[pos ? (int)c0 + m + 1 : (int)c0 - m] - oa) / da;
+    }
+    head = next;
+    return pos ? c0 + (uint32_t)m : c0 - (uint32_t)m;
+}
+
+// What a ray's entries are made from: its DDA start state (:351-362, :383-385), where it ends, how many cells it will visit if
+// it hits nothing, and into how many segments it is cut.
+struct EntryPlan { DdaState start; uint32_t endCell, visits, nseg; float te; };
+
+__device__ __forceinline__ EntryPlan plan_entries(const float *planes, V3 o, V3 d, float tmin, float tmax, uint32_t segLen)
+{
+    EntryPlan p;
+    const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
+    const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
+    // start / end cells (:351-362)
+    int cx = 0, cy = 0, cz = 0, ex = 0, ey = 0, ez = 0;
+    V3 from = along(o, tmin, d);
+    bind_in_cube(from, d, lo, hi);
+#pragma unroll
+    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+        if (planes[cx + div] < from.x) cx += div;
+        if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
+        if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
+    }
+    p.start.cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
+    p.te = RT_INF;
+    V3 to;
+    if (tmax < RT_INF) {
+        to = along(o, tmax, d);
+        bind_in_cube(to, d, lo, hi);
+    } else {
+        // where the ray leaves the grid: the smallest of the three boundary crossings (same quotients as the walk's)
+        if (d.x != 0.f) { const float t = (((0.f <= d.x) ? hi.x : lo.x) - o.x) / d.x; if (t < p.te) p.te = t; }
+        if (d.y != 0.f) { const float t = (((0.f <= d.y) ? hi.y : lo.y) - o.y) / d.y; if (t < p.te) p.te = t; }
+        if (d.z != 0.f) { const float t = (((0.f <= d.z) ? hi.z : lo.z) - o.z) / d.z; if (t < p.te) p.te = t; }
+        to = (p.te < RT_INF) ? along(o, p.te, d) : from;
+    }
+#pragma unroll
+    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+        if (planes[ex + div] < to.x) ex += div;
+        if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
+        if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
+    }
+    // (where a ray without an end cell leaves the grid is a scheduling matter only)
+    p.endCell = (tmax < RT_INF) ? ((uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16)) : 0xffffffffu;
+    // distances from the ray ORIGIN to the next plane of each axis (:383-385)
+    p.start.dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
+    p.start.dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
+    p.start.dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
+    // every step moves one axis by one cell in a fixed direction: visits = Manhattan distance + 1
+    p.visits = (uint32_t)(abs(ex - cx) + abs(ey - cy) + abs(ez - cz)) + 1u;
+    p.nseg = 1;
+    // Only rays without an end cell are cut, and only where every quotient involved is an ordinary number (a zero
+    // direction component makes heads infinite or NaN and the merge argument is not worth stretching to them).
+    const float ta = fminf(p.start.dx, fminf(p.start.dy, p.start.dz));
+    const bool plain = !(tmax < RT_INF) && d.x != 0.f && d.y != 0.f && d.z != 0.f && p.te < RT_INF && -RT_INF < ta && ta < p.te &&
+                       p.start.dx == p.start.dx && p.start.dy == p.start.dy && p.start.dz == p.start.dz && p.start.dx < RT_INF &&
+                       p.start.dy < RT_INF && p.start.dz < RT_INF;
+    if (plain && p.visits > segLen + segLen / 4) { // a ray only slightly over the aim is left whole
+        p.nseg = (p.visits + segLen - 1) / segLen;
+        if (p.nseg > RT_WF_MAXSEG) p.nseg = RT_WF_MAXSEG;
+    }
+    return p;
 }
 
 // ---- stage 2: per-path state machine ---------------------------------------------------------------------------------
@@ -302,14 +414,25 @@ __device__ __forceinline__ void load_tri_row(const RtDevScene &S, uint32_t tri, 
 }
 
 // FIRST = round 0: every entry is a primary hit (stage, ring positions and the colour so far are known), a path's id is its queue index.
+// slicesIn = queue slices per kind of THIS round (what logic(round - 1) was told), next = how the round this launch spawns is laid out.
 template <bool FIRST>
-__global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+__global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
+                                                                                                             const uint32_t slicesIn, const RtRoundMode next)
 {
-    __shared__ Shared sh; // only the texel/255 table is used here
+    __shared__ Shared sh; // the texel/255 table and the split planes (for the entries of the rays spawned here)
     // the first RT_WF_LIGHTS_LDS lights, one LDS read away instead of a chain of small global loads per light and state
     __shared__ float4 ltPosRadius[RT_WF_LIGHTS_LDS], ltDirSpread[RT_WF_LIGHTS_LDS], ltColHalf[RT_WF_LIGHTS_LDS];
     __shared__ int ltType[RT_WF_LIGHTS_LDS];
+    // an ordered round's classes, per wave: entries of this wave per walk-length class, then where the class's ranks of this wave start
+    __shared__ uint32_t waveHist[4][RT_WF_SORT_BINS], waveBase[4][RT_WF_SORT_BINS];
+    __shared__ uint8_t itemOwner[4][64 * (RT_WF_MAXSEG - 1)]; // per wave: which lane's ray the i-th further segment belongs to
+    static_assert(RT_WF_SORT_BINS == 64, "one class per lane");
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
+    {
+        float *pl = &sh.planes[0][0];
+        for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) pl[i] = S.boxMin[i];
+        waveHist[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
+    }
     if (threadIdx.x < RT_WF_LIGHTS_LDS && threadIdx.x < S.lightCount) {
         const uint32_t k = threadIdx.x;
         ltType[k] = S.lightType[k];
@@ -330,34 +453,51 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
     };
 
     const uint32_t in = round & 1, outq = in ^ 1;
-    const uint32_t *countIn = W.counts + (round % 3) * RT_WF_QSHARDS;
-    uint32_t *countOut = W.counts + ((round + 1) % 3) * RT_WF_QSHARDS;
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t *ctlIn = W.ctl + (round % 3) * RT_WF_CTL_WORDS;
+    uint32_t *ctlOut = W.ctl + ((round + 1) % 3) * RT_WF_CTL_WORDS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t waveId = (blockIdx.x * 256 + threadIdx.x) >> 6, waves = (gridDim.x * 256) >> 6;
     Counters cn; // unused (COUNT=false instantiations below)
-    // in-stream housekeeping: the queue counters two rounds ahead and the histogram of this round's sort
+    // in-stream housekeeping: the control words two rounds ahead (queue lengths, class histogram, region B's fill)
     {
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-        if (gid < RT_WF_QSHARDS) W.counts[((round + 2) % 3) * RT_WF_QSHARDS + gid] = 0u;
-        if (gid < RT_WF_SORT_COPIES * RT_WF_SORT_BINS) W.sortHist[gid] = 0u;
-        if (gid == 0) { W.sortExtra[0] = 0u; W.sortTotal[0] = 0u; } // (a sorted round overwrites sortTotal in wf_scatter_kernel)
+        if (gid < RT_WF_CTL_WORDS) W.ctl[((round + 2) % 3) * RT_WF_CTL_WORDS + gid] = 0u;
+    }
+    // for the launch plan: this round's rays and its longest queue slice (one workgroup adds up the RT_WF_QSHARDS queue lengths)
+    if (blockIdx.x == gridDim.x - 1 && round < RT_WF_ROUND_LOG) {
+        __shared__ uint32_t sumWave[4], maxWave[4];
+        static_assert(RT_WF_QSHARDS == 512, "two queue lengths per thread");
+        const uint32_t c0 = ctlIn[RT_WF_CTL_COUNTS + threadIdx.x], c1 = ctlIn[RT_WF_CTL_COUNTS + 256 + threadIdx.x];
+        uint32_t n = c0 + c1, m = max(c0, c1);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { n += __shfl_xor(n, off, 64); m = max(m, (uint32_t)__shfl_xor((int)m, off, 64)); }
+        if (lane == 0) { sumWave[wave] = n; maxWave[wave] = m; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t *log = reinterpret_cast<uint32_t *>(W.roundLog + round);
+            log[0] = sumWave[0] + sumWave[1] + sumWave[2] + sumWave[3];
+            log[1] = max(max(maxWave[0], maxWave[1]), max(maxWave[2], maxWave[3]));
+        }
     }
     const bool multiLight = S.lightCount > 1u;
+    const float *planes = &sh.planes[0][0];
 
-    // main requests only (slices [0, RT_WF_SHARDS)): one per waiting path; look-ahead answers are picked up by index.
+    // main entries only (slices [0, slicesIn)): one per waiting path; look-ahead answers are picked up by index.
     // The grid is a whole number of waves per slice (rtw_launch_logic), so a wave stays in ONE slice and needs its length only:
-    // slice = wave id % RT_WF_SHARDS, chunks of 64 entries dealt to the slice's waves in turn.
+    // slice = wave id % slicesIn, chunks of 64 entries dealt to the slice's waves in turn.
     // (wave-uniform values are told to be so: they live in scalar registers, not in one of the few vector registers left)
-    const uint32_t shard = __builtin_amdgcn_readfirstlane(waveId % RT_WF_SHARDS);
-    const uint32_t total = __builtin_amdgcn_readfirstlane(countIn[shard]);
-    for (uint32_t localChunk = __builtin_amdgcn_readfirstlane(waveId / RT_WF_SHARDS); localChunk * 64 < total; localChunk += waves / RT_WF_SHARDS) {
+    const uint32_t shard = __builtin_amdgcn_readfirstlane(waveId % slicesIn);
+    const uint32_t total = __builtin_amdgcn_readfirstlane(ctlIn[RT_WF_CTL_COUNTS + shard]);
+    const uint32_t sliceCapIn = W.capacity / slicesIn, sliceCapOut = W.capacity / next.slices;
+    const uint32_t outShard = shard % next.slices; // (slices never grow from one round to the next: a slice holds at most the paths of its shards)
+    for (uint32_t localChunk = __builtin_amdgcn_readfirstlane(waveId / slicesIn); localChunk * 64 < total; localChunk += waves / slicesIn) {
         const uint32_t local = localChunk * 64 + lane;
-        const uint32_t q = shard * W.shardCap + local;
+        const uint32_t q = shard * sliceCapIn + local;
         const bool live = local < total;
 #ifdef RT_DIAG_LOGIC
-        unsigned long long dg[10];
+        unsigned long long dg[12];
         dg[0] = diag_stamp();
-        for (int i = 1; i < 10; ++i) dg[i] = 0;
+        for (int i = 1; i < 12; ++i) dg[i] = 0;
 #endif
         bool emit = false, emitLa = false;
         V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), lo3 = mk(0, 0, 0), ld3v = mk(0, 0, 0);
@@ -382,9 +522,8 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                 const uint4 r = W.res[q];
                 res_tri = r.x; res_t = __uint_as_float(r.y); res_l1 = __uint_as_float(r.z); res_l2 = __uint_as_float(r.w);
             } else {
-                const uint2 rx = W.reqX[in][q];
-                key = W.hitKey[q];
-                a = rx.y;
+                a = W.pathOf[in][q];
+                key = W.hitKey[in][q];
             }
             float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
             uint64_t rng = W.rng[a];
@@ -410,7 +549,7 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
             uint32_t j = meta.z >> 16;
             DG(1);
             bool laFetched = false;
-            if (laState == 1u) { laKey = W.hitKey[W.laSlot[a]]; laState = 2u; laFetched = true; }
+            if (laState == 1u) { laKey = W.hitKey[in][W.laSlot[a]]; laState = 2u; laFetched = true; }
             else if (laState == 2u) laKey = W.laKey[a];
 
             // the ray in flight (ring slot `head`), loaded when its answer is here
@@ -432,9 +571,13 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                 const float4 sp = W.shP[a], sf = W.shFace[a];
                 P = xyz(sp); ndl = sp.w; face = xyz(sf); front = (sf.w != 0.f);
                 if (attStored) atten = xyz(W.shAtt[a]);
-                // the request that was answered still holds the hit point and the direction to the light
-                qo = W.reqO[in][q]; qd = W.reqD[in][q];
-                where = xyz(qo); lmin = qo.w; toL = xyz(qd); lmax = qd.w;
+                // the entry that was answered still holds the hit point and the direction to the light: {..} {.., tmin} {o, tmax} {d, ..}
+                {
+                    const float4 *e = reinterpret_cast<const float4 *>(W.ent[in]) + 4 * (size_t)q;
+                    const float4 e1 = e[1];
+                    qo = e[2]; qd = e[3];
+                    where = xyz(qo); lmin = e1.w; toL = xyz(qd); lmax = qo.w;
+                }
                 if (multiLight) { n = xyz(W.shN[a]); rngL = W.rngL[a]; }
                 res_tri = resolve_hit(S, key, where, toL, lmin, lmax, hit_tri, res_t, res_l1, res_l2);
                 pc = PC_SHADOW_RESULT;
@@ -682,391 +825,246 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
                 }
             }
         }
-        // every lane of the wave arrives here: one atomic per wave and queue slice for the requests of the next round
+        // Every lane of the wave arrives here: one atomic instruction for the wave's two queue appends.
         uint32_t slot, slotLa;
-        wave_append2(&countOut[shard], emit, &countOut[RT_WF_SHARDS + shard], emitLa, slot, slotLa);
-        slot += shard * W.shardCap;
-        slotLa += (RT_WF_SHARDS + shard) * W.shardCap;
-        asm volatile("" : "+v"(a), "+v"(slot), "+v"(slotLa)); // (same for the request stores: addresses made here, not carried)
+        wave_append2(&ctlOut[RT_WF_CTL_COUNTS + outShard], emit, &ctlOut[RT_WF_CTL_COUNTS + RT_WF_SHARDS + outShard], emitLa, slot, slotLa);
+        slot += outShard * sliceCapOut;
+        slotLa += W.capacity + outShard * sliceCapOut;
+        asm volatile("" : "+v"(a), "+v"(slot), "+v"(slotLa)); // (addresses made here, not carried across the state machine)
         if (slot != 0xfffffff0u) DG(8);
-        if (emit) {
-            W.reqO[outq][slot] = pack4(ro, rtmin);
-            W.reqD[outq][slot] = pack4(rd, rtmax);
-            W.reqX[outq][slot] = make_uint2(rexcl, a);
+        // The rays of the next round become TRACE ENTRIES now: DDA start state, segments, and -- for a round that will be ordered --
+        // the walk-length class of every entry (stage "trace entries" above).  Main rays first, then the look-ahead rays: one plan
+        // in registers at a time.
+        uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0; // ordered round: segment 0's class and its rank inside this wave
+        uint32_t itemsM = 0, itemsL = 0, itemsAtM = 0, itemsAtL = 0; // further segments of this wave's main / look-ahead rays: how many, and where in region B
+        const uint32_t copy = waveId % RT_WF_SORT_COPIES;
+        // walk-length class of an entry that will make v cell visits if it hits nothing (scheduling only).  Two scales: segments of a
+        // finely cut round differ by a few visits, uncut rays by hundreds; class 0 = longest
+        auto visit_class = [](uint32_t v) -> uint32_t {
+            if ((int)v < 1) v = 1;
+            if (v > 767u) v = 767u;
+            return (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+        };
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const bool has = which ? emitLa : emit;
+            if (__ballot(has) == 0ull) continue; // wave-uniform
+            const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
+            const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
+            const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
+            EntryPlan plan;
+            plan.nseg = 0; plan.visits = 1; plan.endCell = 0xffffffffu; plan.te = RT_INF;
+            plan.start.cell = 0; plan.start.dx = 0.f; plan.start.dy = 0.f; plan.start.dz = 0.f;
+#ifdef RT_X_FAKEPLAN
+            if (has) { plan.nseg = 1; plan.start.cell = (__float_as_uint(o.x) & 0xffffffu); plan.start.dx = o.x; plan.start.dy = o.y; plan.start.dz = o.z; plan.visits = 100; }
+#else
+            if (has) plan = plan_entries(planes, o, d, tmin, tmax, next.segLen);
+#endif
+            uint32_t nseg = plan.nseg, extraAt = 0, items = 0, before = 0;
+            // Room in region B for the further segments of this wave's rays: one atomic per wave that cuts anything.  A reservation is
+            // never undone (an add followed by a subtract is not atomic across waves: a later, smaller reservation could land inside
+            // the range the subtract gives back).  A count past extraCap just means "region B is full"; every reader clamps it.  The
+            // one wave whose range straddles the end owns [at, extraCap) and marks those slots empty; waves after it start past the
+            // end and own nothing.  No room, no cutting: the wave's rays stay whole.
+            if (__ballot(nseg > 1u) != 0ull) { // wave-uniform
+                const uint32_t extraMine = nseg > 1u ? nseg - 1u : 0u;
+                uint32_t incl = extraMine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(incl, off, 64);
+                    if ((int)lane >= off) incl += up;
+                }
+                items = (uint32_t)__shfl((int)incl, 63, 64);
+                before = incl - extraMine;
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(&ctlOut[RT_WF_CTL_EXTRA], items);
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                if ((uint64_t)base + items > (uint64_t)W.extraCap) {
+                    for (uint32_t i = base + lane; i < W.extraCap; i += 64) {
+                        W.ent[outq][4 * (size_t)(2u * W.capacity + i)].x = 0xffffffffu;
+                        W.sortRank[2u * W.capacity + i] = 0xffffffffu;
+                    }
+                    if (nseg > 1u) nseg = 1u;
+                    items = 0;
+                }
+                extraAt = 2u * W.capacity + base; // region B of the entry array starts after the 2*capacity queue slots
+                // who owns item i (= further segment before + j - 1 of lane `owner`)
+                for (uint32_t j = 1; j < nseg; ++j) itemOwner[wave][before + j - 1] = (uint8_t)lane;
+            }
+            if (which) { itemsL = items; itemsAtL = extraAt; } else { itemsM = items; itemsAtM = extraAt; }
+            // Segment k of a ray goes from the walk's state at tau_k to the start cell of segment k + 1 (tau_0 = the ray's own start):
+            // tau_k = ta + (te - ta) * k / nseg is non-decreasing in k and a cut only exists where ta <= tau_k < te, so the cuts that
+            // exist are a prefix of 1 .. nseg - 1 -- every lane can tell from k alone whether cut k and cut k + 1 exist.
+            const float ta = fminf(plan.start.dx, fminf(plan.start.dy, plan.start.dz));
+            const uint32_t perSeg = nseg ? (plan.visits + nseg - 1) / nseg : 1u;
+            auto cut_at = [](float ta_, float te_, uint32_t k, uint32_t n, float &tau) -> bool {
+                tau = ta_ + (te_ - ta_) * ((float)k / (float)n);
+                return ta_ <= tau && tau < te_;
+            };
+            if (has) { // segment 0, at the ray's queue index; where it ends is filled in by the lane that makes cut 1
+                W.pathOf[outq][mine] = a;
+                W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
+                if (which) W.laSlot[a] = mine;
+                float tau1;
+                const bool cut1 = nseg > 1u && cut_at(ta, plan.te, 1u, nseg, tau1);
+                uint32_t tag = 0u, rank = 0u;
+                if (next.ordered) {
+                    const uint32_t bin = visit_class(cut1 ? perSeg : plan.visits);
+                    rank = atomicAdd(&waveHist[wave][bin], 1u);
+                    tag = bin;
+                    if (which) { binL = bin; rankL = rank; } else { binM = bin; rankM = rank; }
+                }
+                uint4 *e = W.ent[outq] + 4 * (size_t)mine;
+                if (nseg > 1u) { // (.z comes from another lane: not written here, so that the two stores cannot meet)
+                    *reinterpret_cast<uint2 *>(e) = make_uint2(mine, plan.start.cell | (tag << 24));
+                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
+                } else e[0] = make_uint4(mine, plan.start.cell | (tag << 24), plan.endCell, excluded);
+#ifndef RT_X_NOENTSTORE
+                e[1] = make_uint4(__float_as_uint(plan.start.dx), __float_as_uint(plan.start.dy), __float_as_uint(plan.start.dz), __float_as_uint(tmin));
+                e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+                e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank); // (rank inside this wave's class for now; segment 0)
+#endif
+            }
+            if (items == 0u) continue; // wave-uniform
+            // The further segments, one per lane whoever's ray it is: a lane that shades one of the few hits of a late round would
+            // otherwise make its ray's up to 11 cuts one after the other while the wave's other lanes wait (measured: 40 % of a chunk's time).
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i0 = 0; i0 < items; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool live = i < items;
+                const uint32_t owner = live ? itemOwner[wave][i] : 0u;
+                const uint32_t k = i - (uint32_t)__shfl((int)before, owner, 64) + 1u; // this lane makes cut k of `owner`'s ray
+                const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+                const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+                const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64), pta = __shfl(ta, owner, 64), pte = __shfl(plan.te, owner, 64);
+                const uint32_t pexcl = __shfl(excluded, owner, 64), pmine = __shfl(mine, owner, 64), pcell = __shfl(plan.start.cell, owner, 64);
+                const uint32_t pnseg = __shfl(nseg, owner, 64), pvisits = __shfl(plan.visits, owner, 64), pend = __shfl(plan.endCell, owner, 64);
+                if (!live) continue;
+                const uint32_t at = extraAt + i; // entry of segment k
+                float tau, tauNext;
+                const bool cut = cut_at(pta, pte, k, pnseg, tau);
+                const bool cutNext = k + 1u < pnseg && cut_at(pta, pte, k + 1u, pnseg, tauNext);
+                uint32_t *prev = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)(k == 1u ? pmine : at - 1u));
+                uint32_t *self = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)at);
+                if (!cut) { // rounding left no room for this cut: the segment before runs to the ray's end, this one does not exist
+                    prev[2] = pend;
+                    self[0] = 0xffffffffu;
+                    W.sortRank[at] = 0xffffffffu;
+                    continue;
+                }
+                DdaState st;
+                // (counting the crossings with T <= tau from the ray's start cell: the state does not depend on where counting begins)
+                const uint32_t nx = axis_state_at(planes, pcell & 255u, po.x, pd.x, tau, st.dx);
+                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (pcell >> 8) & 255u, po.y, pd.y, tau, st.dy);
+                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), pcell >> 16, po.z, pd.z, tau, st.dz);
+                st.cell = nx | (ny << 8) | (nz << 16);
+                prev[2] = st.cell; // the segment before ends where this one starts
+                uint32_t tag = 0u, rank = 0u;
+                if (next.ordered) {
+                    const uint32_t per = (pvisits + pnseg - 1) / pnseg;
+                    const uint32_t bin = visit_class(cutNext ? per : pvisits - per * k);
+                    rank = atomicAdd(&waveHist[wave][bin], 1u);
+                    tag = bin;
+                }
+                *reinterpret_cast<uint2 *>(self) = make_uint2(pmine, st.cell | (tag << 24));
+                self[3] = pexcl;
+                if (!cutNext) self[2] = pend; // the ray's last segment
+                uint4 *e = reinterpret_cast<uint4 *>(self);
+                e[1] = make_uint4(__float_as_uint(st.dx), __float_as_uint(st.dy), __float_as_uint(st.dz), __float_as_uint(ptmin));
+                e[2] = make_uint4(__float_as_uint(po.x), __float_as_uint(po.y), __float_as_uint(po.z), __float_as_uint(ptmax));
+                e[3] = make_uint4(__float_as_uint(pd.x), __float_as_uint(pd.y), __float_as_uint(pd.z), rank | (k << 24));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // (itemOwner is rewritten for the look-ahead rays)
         }
-        if (emitLa) {
-            W.reqO[outq][slotLa] = pack4(lo3, latmin);
-            W.reqD[outq][slotLa] = pack4(ld3v, RT_INF);
-            W.reqX[outq][slotLa] = make_uint2(laexcl, a);
-            W.laSlot[a] = slotLa;
+        if (copy != 0xfffffff0u) DG(9);
+#ifdef RT_X_NOHIST
+        if (false) {
+#else
+        if (next.ordered) {
+#endif
+            // rank inside the (class, copy) = this wave's base + rank inside the wave: lane b fetches the base of class b (one atomic
+            // instruction for the wave's up to 64 classes).  One wave, in-order LDS: wavefront-scope fences are all the ordering needed.
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                uint32_t l2 = lane;
+                asm volatile("" : "+v"(l2)); // (the address is made here: hoisted out of the chunk loop it was spilled, and its reload waited for every store in flight)
+                const uint32_t n = waveHist[wave][l2];
+                waveBase[wave][l2] = n ? atomicAdd(&ctlOut[RT_WF_CTL_HIST + copy * RT_WF_SORT_BINS + l2], n) : 0u;
+                waveHist[wave][l2] = 0u; // (for this wave's next chunk)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (emit) { W.sortRank[slot] = waveBase[wave][binM] + rankM; W.sortTag[slot] = (uint16_t)(binM | (copy << 6)); }
+            if (emitLa) { W.sortRank[slotLa] = waveBase[wave][binL] + rankL; W.sortTag[slotLa] = (uint16_t)(binL | (copy << 6)); }
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) { // the further segments: class and rank in the wave are in the entries
+                const uint32_t items = which ? itemsL : itemsM, at0 = which ? itemsAtL : itemsAtM;
+                for (uint32_t i = lane; i < items; i += 64) {
+                    const uint4 *e = W.ent[outq] + 4 * (size_t)(at0 + i);
+                    if (e[0].x == 0xffffffffu) continue;
+                    const uint32_t bin = e[0].y >> 24;
+                    W.sortRank[at0 + i] = waveBase[wave][bin] + (e[3].w & 0xffffffu);
+                    W.sortTag[at0 + i] = (uint16_t)(bin | (copy << 6));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // (waveBase is overwritten by this wave's next chunk)
         }
+        if (copy != 0xfffffff0u) DG(10);
 #ifdef RT_DIAG_LOGIC
         if (round == RT_DIAG_LOGIC) {
-            dg[9] = diag_stamp();
+            dg[11] = diag_stamp();
             // a stamp taken in a divergent branch belongs to the wave: take the latest any lane saw, and keep the sequence monotone
-            for (int i = 1; i < 10; ++i) {
+            for (int i = 1; i < 12; ++i) {
                 unsigned long long v = dg[i];
                 for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o2 = __shfl_xor((long long)v, off, 64); v = v > o2 ? v : o2; }
                 dg[i] = v > dg[i - 1] ? v : dg[i - 1];
             }
-            if (lane == 0) {
-                for (int i = 0; i < 7; ++i) atomicAdd(&S.stats[i], dg[i + 1] - dg[i]);
-                atomicAdd(&S.stats[7], dg[9] - dg[7]);
+            if (lane == 0) { // machine | look-ahead pick | append atomics | entries | classes + ranks | rest | chunks | whole chunk
+                atomicAdd(&S.stats[0], dg[6] - dg[0]); atomicAdd(&S.stats[1], dg[7] - dg[6]); atomicAdd(&S.stats[2], dg[8] - dg[7]);
+                atomicAdd(&S.stats[3], dg[9] - dg[8]); atomicAdd(&S.stats[4], dg[10] - dg[9]); atomicAdd(&S.stats[5], dg[11] - dg[10]);
+                atomicAdd(&S.stats[6], 1ull); atomicAdd(&S.stats[7], dg[11] - dg[0]);
             }
         }
 #endif
     }
 }
 
-// ---- stage 2b: segmented, length-sorted trace input -----------------------------------------------------------------
-// A round lasts as long as its longest dependent chain: a ray that crosses the whole grid makes 766 cell visits one after
-// the other, and measured round times are ~0.4 ms + 0.32 ms per million rays -- the constant is that chain.  The walk is a
-// 3-way merge: per axis, the parameters T_a(i) = (plane_a[i] - o_a) / d_a at which the ray crosses successive planes form a
-// non-decreasing sequence (the same rounded quotients the reference computes, :383-385), and every step takes the smallest
-// head (:387-398).  So the state of the walk after all crossings with T <= tau is, per axis, simply the NUMBER of such
-// crossings -- it can be computed without walking (a plane search plus two exact divides per axis), for any tau.  A long
-// ray is therefore cut into up to RT_WF_MAXSEG SEGMENTS at parameters tau_k: segment k starts in the state at tau_k and ends
-// when it has visited the start cell of segment k+1 (the existing end-cell rule, :380).  Segments are traced as independent
-// entries; the ray's answer is the hit of its lowest segment that has one (atomicMin on hitKey), exactly the first cell
-// with a hit in path order.  Segments after a hit are wasted work; the chain per entry is ~8x shorter.
-//
-// wf_setup_kernel turns every request into its entries (DDA start state computed once, here instead of in the trace
-// kernel), keys them by predicted cell visits and counts them into RT_WF_SORT_BINS classes; wf_scatter_kernel moves the
-// entries to their sorted positions, longest class first.  Only the ORDER and GROUPING in which cells are visited changes.
-// Cutting costs work (every entry has a start-up and a test batch of its own, segments behind a hit are wasted), so the
-// aimed-at cell visits per segment depend on how many rays the round has (RtWavefront::segLen/segRays, rt_api.cpp): a round
-// that fills the GPU several times over is bound by its total work and is not cut at all (cutting at 384/256/192/128 visits
-// measured 1-13 % slower), a round with few rays is cut finely enough to occupy every SIMD.  The levels were tuned on the
-// tile shares of 1, 2, 4 and 8 ranks (scripts/sweep_seg.sh); finer cuts than these move more time into this kernel than
-// they take out of the trace.
-#ifndef RT_WF_MAXSEG
-#define RT_WF_MAXSEG 12
-#endif
-struct DdaState { uint32_t cell; float dx, dy, dz; };
-
-// One axis of the state at parameter tau: c0 = cell coordinate of the walk's start, returns the coordinate after all
-// crossings with T <= tau and, in `head`, the parameter of the next crossing.  `limit` = crossings that stay inside the grid.
-__device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t c0, float oa, float da, float tau, float &head)
+// ---- stage 2b: an ordered round's entries, longest predicted walk first ------------------------------------------------------
+// Queue slice s of a round (s < slices: main entries, s >= slices: look-ahead entries): where it starts and how long it is.
+__device__ __forceinline__ uint32_t slice_first(const RtWavefront &W, uint32_t slices, uint32_t s)
 {
-    const bool pos = (0.f <= da);
-    const int limit = pos ? (int)(RT_GRID_DIV - 1 - c0) : (int)c0; // the crossing after these leaves the grid (tau is before it)
-    // guess from the position (the plane search of GetBoxAddress), then settle it with the exact quotients
-    const float p = oa + tau * da;
-    int g = 0;
-#pragma unroll
-    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2)
-        if (planes[g + div] < p) g += div;
-    int m = pos ? g - (int)c0 : (int)c0 - g;
-    m = m < 0 ? 0 : (m > limit ? limit : m);
-    // crossing number k (1-based) is plane c0+k going up, c0-k+1 going down
-    while (m >= 1 && !((planes[pos ? (int)c0 + m : (int)c0 - m + 1] - oa) / da <= tau)) --m;
-    float next = (planes[pos ? (int)c0 + m + 1 : (int)c0 - m] - oa) / da;
-    while (m < limit && next <= tau) {
-        ++m;
-        next = (planes[pos ? (int)c0 + m + 1 : (int)c0 - m] - oa) / da;
-    }
-    head = next;
-    return pos ? c0 + (uint32_t)m : c0 - (uint32_t)m;
+    const uint32_t kind = (s >= slices) ? 1u : 0u, shard = s - kind * slices;
+    return kind * W.capacity + shard * (W.capacity / slices);
+}
+__device__ __forceinline__ uint32_t slice_count(const uint32_t *ctl, uint32_t slices, uint32_t s)
+{
+    const uint32_t kind = (s >= slices) ? 1u : 0u, shard = s - kind * slices;
+    return ctl[RT_WF_CTL_COUNTS + kind * RT_WF_SHARDS + shard];
 }
 
-// appendedPlan: the host issued no wf_scatter_kernel behind this launch, because this round's entries were appended when the frame
-// was last rendered (rt_api.cpp); if the round has to be sorted after all, the host is told and renders the frame again.
-__global__ __launch_bounds__(256) void wf_setup_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round, const uint32_t appendedPlan)
-{
-    __shared__ float planes[3 * (RT_GRID_DIV + 1)];
-    __shared__ uint32_t binCount[RT_WF_SORT_BINS], binBase[RT_WF_SORT_BINS];
-    __shared__ uint32_t extraWave[4], extraBase, extraVoidAt, extraVoidEnd, raysWave[4], longWave[4], actWave[4], actBase;
-    __shared__ uint32_t sliceCount[RT_WF_QSHARDS]; // the queue lengths, read once (a work item's own length was a second dependent load)
-    static_assert(RT_WF_QSHARDS == 512, "two queue lengths per thread");
-    for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    { // rays of the whole round and the longest queue slice: RT_WF_QSHARDS queue lengths, two per thread
-        const uint32_t c0 = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x], c1 = W.counts[(round % 3) * RT_WF_QSHARDS + 256 + threadIdx.x];
-        sliceCount[threadIdx.x] = c0; sliceCount[256 + threadIdx.x] = c1;
-        uint32_t n = c0 + c1, m = max(c0, c1);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { n += __shfl_xor(n, off, 64); m = max(m, (uint32_t)__shfl_xor((int)m, off, 64)); }
-        if (lane == 0) { raysWave[wave] = n; longWave[wave] = m; }
-    }
-    __syncthreads();
-    const uint32_t roundRays = raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3];
-    const uint32_t longest = max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3]));
-    const uint32_t segLen = roundRays >= W.segRays[0] ? W.segLen[0] : (roundRays >= W.segRays[1] ? W.segLen[1] : (roundRays >= W.segRays[2] ? W.segLen[2] :
-                            (roundRays >= W.segRays[3] ? W.segLen[3] : W.segLen[4])));
-    // A small round is cut into near-equal segments; ordering those by length buys nothing, and the two launches of the
-    // counting sort are a fixed ~50 us.  Such a round's entries are APPENDED straight to the trace input instead: segment 0 of
-    // every ray compactly at the front (sortTotal counts them), further segments in region B (sortExtra counts them), and
-    // wf_scatter_kernel finds nothing to do.
-    const bool append = roundRays < W.appendRays;
-    if (append && blockIdx.x == 0 && threadIdx.x == 0) W.sortTotal[1] = RT_WF_ORDER_APPENDED; // tells the trace kernel that region B is in use
-    if (!append && appendedPlan) { // nothing will order this round's entries (sortTotal stays 0: the trace kernel finds nothing to do)
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
-        return;
-    }
-    // A BIG round is bound by the rate at which L2 misses are served (profiles/r02_*: 36 M 128-byte fabric requests per frame at
-    // ~90 % of the measured random-gather ceiling): its rays meet the same cells at unrelated times, so nearly every cell visit
-    // misses L2.  Such a round is cut at REGION boundaries instead (a region = 64^3 cells, 1/64 of the grid: ~2 MB of pair
-    // records and cell ranges, half an XCD's L2) and its entries are ordered by region; wf_trace_kernel hands every XCD a
-    // contiguous stretch of that order, so the workgroups in flight on an XCD work in the same one or two regions.
-    const bool regionMode = !append && roundRays >= W.regionRays;
-    // Queue slices are sized for the worst case and filled evenly, so the work items are (slice, 256-entry block) pairs up to the
-    // longest slice, taken block-major by a fixed grid (a grid over the whole capacity is mostly workgroups that exit at once:
-    // ~0.35 us per 1000 of them, a quarter of a millisecond per 4K frame).
-    const uint32_t usedBlocks = (longest + 255u) >> 8;
-    for (uint32_t item = blockIdx.x; item < RT_WF_QSHARDS * usedBlocks; item += gridDim.x) {
-    const uint32_t shard = item % RT_WF_QSHARDS;
-    const uint32_t local0 = (item / RT_WF_QSHARDS) * 256;
-    const uint32_t total = sliceCount[shard];
-    if (local0 >= total) continue; // workgroup-uniform: this slice is shorter
-    __syncthreads(); // the previous item's LDS counters have been read by everybody
-    if (threadIdx.x < RT_WF_SORT_BINS) binCount[threadIdx.x] = 0u;
-    __syncthreads();
-
-    const uint32_t in = round & 1;
-    const uint32_t mine = shard * W.shardCap + local0 + threadIdx.x;
-    const bool active = local0 + threadIdx.x < total;
-    const uint32_t copy = item % RT_WF_SORT_COPIES;
-    const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
-    const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
-    V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
-    float tmin = 0.f, tmax = 0.f, te = RT_INF;
-    uint32_t excluded = RT_NONE, endCell = 0xffffffffu, lastCell = 0, visits = 1, nseg = 0;
-    DdaState cur;
-    cur.cell = 0; cur.dx = 0.f; cur.dy = 0.f; cur.dz = 0.f;
-    float cut[9]; // region mode: the ray's cut parameters in ascending order, +inf when there are fewer
-#pragma unroll
-    for (int i = 0; i < 9; ++i) cut[i] = RT_INF;
-    if (active) {
-        const float4 ro = W.reqO[in][mine], rd = W.reqD[in][mine];
-        o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w;
-        excluded = W.reqX[in][mine].x;
-        W.hitKey[mine] = ~0ull; // no segment of this request has a hit yet (after the loads: a wait for them would wait for this store too)
-        // start / end cells (:351-362)
-        int cx = 0, cy = 0, cz = 0, ex = 0, ey = 0, ez = 0;
-        V3 from = along(o, tmin, d);
-        bind_in_cube(from, d, lo, hi);
-#pragma unroll
-        for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-            if (planes[cx + div] < from.x) cx += div;
-            if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
-            if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
-        }
-        cur.cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
-        V3 to;
-        if (tmax < RT_INF) {
-            to = along(o, tmax, d);
-            bind_in_cube(to, d, lo, hi);
-        } else {
-            // where the ray leaves the grid: the smallest of the three boundary crossings (same quotients as the walk's)
-            if (d.x != 0.f) { const float t = (((0.f <= d.x) ? hi.x : lo.x) - o.x) / d.x; if (t < te) te = t; }
-            if (d.y != 0.f) { const float t = (((0.f <= d.y) ? hi.y : lo.y) - o.y) / d.y; if (t < te) te = t; }
-            if (d.z != 0.f) { const float t = (((0.f <= d.z) ? hi.z : lo.z) - o.z) / d.z; if (t < te) te = t; }
-            to = (te < RT_INF) ? along(o, te, d) : from;
-        }
-#pragma unroll
-        for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-            if (planes[ex + div] < to.x) ex += div;
-            if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
-            if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
-        }
-        lastCell = (uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16); // scheduling only, unless the ray has an end cell
-        if (tmax < RT_INF) endCell = lastCell;
-        // distances from the ray ORIGIN to the next plane of each axis (:383-385)
-        cur.dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
-        cur.dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
-        cur.dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
-        // every step moves one axis by one cell in a fixed direction: visits = Manhattan distance + 1
-        visits = (uint32_t)(abs(ex - cx) + abs(ey - cy) + abs(ez - cz)) + 1u;
-        nseg = 1;
-        // Only rays without an end cell are cut, and only where every quotient involved is an ordinary number (a zero
-        // direction component makes heads infinite or NaN and the merge argument is not worth stretching to them).
-        const float ta = fminf(cur.dx, fminf(cur.dy, cur.dz));
-        const bool plain = !(tmax < RT_INF) && d.x != 0.f && d.y != 0.f && d.z != 0.f && te < RT_INF && -RT_INF < ta && ta < te &&
-                           cur.dx == cur.dx && cur.dy == cur.dy && cur.dz == cur.dz && cur.dx < RT_INF && cur.dy < RT_INF && cur.dz < RT_INF;
-        if (plain && regionMode) {
-            // Cut points = the parameters at which the ray crosses a region boundary plane (plane index 64, 128, 192 of an axis,
-            // ahead of the start cell in the direction of travel): the same rounded quotients the walk compares, so each is a
-            // legal cut (the state after all crossings with T <= tau), and between two consecutive ones the walk stays inside
-            // one region.  At most three per axis; those at or beyond the exit do not cut anything.
-            const float ta0 = fminf(cur.dx, fminf(cur.dy, cur.dz));
-            const float oa[3] = { o.x, o.y, o.z }, da[3] = { d.x, d.y, d.z };
-            const int c0[3] = { cx, cy, cz };
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                for (int j = 1; j <= 3; ++j) {
-                    const int p = j << RT_WF_REGION_SHIFT;
-                    const bool ahead = (0.f <= da[a]) ? (p > c0[a]) : (p <= c0[a]);
-                    const float T = (planes[a * (RT_GRID_DIV + 1) + p] - oa[a]) / da[a];
-                    cut[a * 3 + j - 1] = (ahead && ta0 <= T && T < te) ? T : RT_INF;
-                }
-            }
-            // ascending order, unused slots (+inf) last: a 9-input sorting network (25 compare-exchanges)
-#define RT_CX(i, j) { const float lo_ = fminf(cut[i], cut[j]), hi_ = fmaxf(cut[i], cut[j]); cut[i] = lo_; cut[j] = hi_; }
-            RT_CX(0, 1) RT_CX(3, 4) RT_CX(6, 7) RT_CX(1, 2) RT_CX(4, 5) RT_CX(7, 8) RT_CX(0, 1) RT_CX(3, 4) RT_CX(6, 7) RT_CX(0, 3) RT_CX(3, 6) RT_CX(0, 3)
-            RT_CX(1, 4) RT_CX(4, 7) RT_CX(1, 4) RT_CX(2, 5) RT_CX(5, 8) RT_CX(2, 5) RT_CX(1, 3) RT_CX(5, 7) RT_CX(2, 6) RT_CX(4, 6) RT_CX(2, 4) RT_CX(2, 3)
-            RT_CX(5, 6)
-#undef RT_CX
-            uint32_t n = 0;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) n += (cut[i] < RT_INF) ? 1u : 0u;
-            nseg = n + 1u;
-        } else if (plain && visits > segLen + segLen / 4) { // a ray only slightly over the aim is left whole
-            nseg = (visits + segLen - 1) / segLen;
-            if (nseg > RT_WF_MAXSEG) nseg = RT_WF_MAXSEG;
-        }
-    }
-    // room for the extra entries (segments 1..) of this workgroup's rays: one atomic per workgroup; no room, no cutting
-    uint32_t extraAt = 0;
-    {
-        const uint32_t mineExtra = nseg ? nseg - 1u : 0u;
-        uint32_t incl = mineExtra;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += up;
-        }
-        if (lane == 63) extraWave[wave] = incl;
-        const unsigned long long actMask0 = __ballot(active);
-        if (lane == 0) actWave[wave] = (uint32_t)__popcll(actMask0);
-        __syncthreads();
-        const uint32_t sum = extraWave[0] + extraWave[1] + extraWave[2] + extraWave[3];
-        if (threadIdx.x == 0) {
-            // (an appended round's second atomic -- where segment 0 of this workgroup's rays goes -- travels with the first)
-            uint32_t appendBase = 0;
-            if (append) appendBase = atomicAdd(&W.sortTotal[0], actWave[0] + actWave[1] + actWave[2] + actWave[3]);
-            // A reservation is never undone (an add followed by a subtract is not atomic across workgroups: a later, smaller
-            // reservation could land inside the range the subtract gives back).  A count past extraCap just means "region B is
-            // full"; every reader clamps it.  The one workgroup whose range straddles the end owns [at, extraCap) and marks
-            // those slots empty; workgroups after it start past the end and own nothing.
-            uint32_t at = sum ? atomicAdd(&W.sortExtra[0], sum) : 0u;
-            extraVoidAt = 0u; extraVoidEnd = 0u;
-            if (sum && (uint64_t)at + sum > (uint64_t)W.extraCap) {
-                if (at < W.extraCap) { extraVoidAt = at; extraVoidEnd = W.extraCap; }
-                at = 0xffffffffu;
-            }
-            extraBase = at;
-            actBase = appendBase;
-        }
-        __syncthreads();
-        uint32_t before = incl - mineExtra;
-        for (uint32_t w = 0; w < wave; ++w) before += extraWave[w];
-        if (extraBase == 0xffffffffu) { // no room: this workgroup's rays stay whole
-            uint4 *ent = append ? W.sortedEnt : W.stageEnt;
-            for (uint32_t i = extraVoidAt + threadIdx.x; i < extraVoidEnd; i += 256) {
-                ent[4 * (size_t)(2u * W.capacity + i)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
-                W.sortRank[2u * W.capacity + i] = 0xffffffffu;
-            }
-            if (nseg > 1) nseg = 1;
-        }
-        else extraAt = 2u * W.capacity + extraBase + before; // region B of the entry arrays starts after the 2*capacity queue slots
-    }
-    uint32_t rank0 = 0, bin0 = 0; // sorted mode: segment 0's class and its rank inside this workgroup
-    uint32_t appendAt = 0; // append mode: where segment 0 of this lane's ray goes
-    if (append) {
-        const unsigned long long actMask = __ballot(active);
-        appendAt = actBase + (uint32_t)__popcll(actMask & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; ++w) appendAt += actWave[w];
-    }
-    // the entries of this lane's ray: segment k goes from the state at tau_k to the start cell of segment k+1
-    const float ta = fminf(cur.dx, fminf(cur.dy, cur.dz));
-    const uint32_t perSeg = nseg ? (visits + nseg - 1) / nseg : 1u;
-    for (uint32_t k = 0; k < nseg; ++k) {
-        DdaState nxt = cur;
-        uint32_t segEnd = endCell;
-        bool last = (k + 1 == nseg);
-        if (!last) {
-            float tau = ta + (te - ta) * ((float)(k + 1) / (float)nseg);
-            if (regionMode) { // cut[k], picked without indexing registers dynamically
-                tau = cut[0];
-#pragma unroll
-                for (int i = 1; i < 9; ++i) tau = (k == (uint32_t)i) ? cut[i] : tau;
-            }
-            if (ta <= tau && tau < te) {
-                const uint32_t c0 = cur.cell & 255u, c1 = (cur.cell >> 8) & 255u, c2 = cur.cell >> 16;
-                // crossings already made by `cur` have T <= tau_k <= tau, so counting from cur's cell is counting from the start
-                const uint32_t nx = axis_state_at(planes, c0, o.x, d.x, tau, nxt.dx);
-                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), c1, o.y, d.y, tau, nxt.dy);
-                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), c2, o.z, d.z, tau, nxt.dz);
-                nxt.cell = nx | (ny << 8) | (nz << 16);
-                segEnd = nxt.cell;
-            } else last = true; // rounding left no room for another cut: this segment runs to the end
-        }
-        uint32_t v = last ? visits - perSeg * k : perSeg; // scheduling key only
-        if ((int)v < 1) v = 1;
-        if (v > 767u) v = 767u;
-        // two scales: segments of a finely cut round differ by a few visits, uncut rays by hundreds; bin 0 = longest
-        uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
-        if (regionMode) // the region the segment starts in: 2 bits per axis
-            bin = ((cur.cell >> RT_WF_REGION_SHIFT) & 3u) | (((cur.cell >> (8 + RT_WF_REGION_SHIFT)) & 3u) << 2) | (((cur.cell >> (16 + RT_WF_REGION_SHIFT)) & 3u) << 4);
-        if (append) { // final place (same layout as a staged entry: no tag, segment in the top byte of the last word)
-            uint4 *e = W.sortedEnt + 4 * (size_t)(k == 0 ? appendAt : extraAt + k - 1);
-            e[0] = make_uint4(mine, cur.cell, segEnd, excluded);
-            e[1] = make_uint4(__float_as_uint(cur.dx), __float_as_uint(cur.dy), __float_as_uint(cur.dz), __float_as_uint(tmin));
-            e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-            e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), k << 24);
-            cur = nxt;
-            if (last) { // unused tail of the reservation: entries the trace kernel skips
-                for (uint32_t r = k + 1; r < nseg; ++r) W.sortedEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u);
-                break;
-            }
-            continue;
-        }
-        const uint32_t rank = atomicAdd(&binCount[bin], 1u);
-        if (k == 0) { rank0 = rank; bin0 = bin; }
-        uint4 *e = W.stageEnt + 4 * (size_t)(k == 0 ? mine : extraAt + k - 1);
-        e[0] = make_uint4(mine, cur.cell | ((bin | (copy << 6)) << 24), segEnd, excluded);
-        e[1] = make_uint4(__float_as_uint(cur.dx), __float_as_uint(cur.dy), __float_as_uint(cur.dz), __float_as_uint(tmin));
-        e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-        e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank | (k << 24)); // rank inside this workgroup's bin for now
-        cur = nxt;
-        if (last) { // unused tail of the reservation: empty entries the scatter kernel drops
-            for (uint32_t r = k + 1; r < nseg; ++r) { W.stageEnt[4 * (size_t)(extraAt + r - 1)] = make_uint4(0xffffffffu, 0u, 0u, 0u); W.sortRank[extraAt + r - 1] = 0xffffffffu; }
-            break;
-        }
-    }
-    if (append) continue; // workgroup-uniform: no ranks to settle
-    __syncthreads();
-    if (threadIdx.x < RT_WF_SORT_BINS) {
-        const uint32_t n = binCount[threadIdx.x];
-        binBase[threadIdx.x] = n ? atomicAdd(&W.sortHist[copy * RT_WF_SORT_BINS + threadIdx.x], n) : 0u;
-    }
-    __syncthreads();
-    // second visit: rank inside the (bin, copy) class = this workgroup's base + rank inside the workgroup.  Segment 0's numbers
-    // are still in registers (most rays have no other: reading the entry back would wait for its own stores and a round trip).
-    if (nseg) { W.sortRank[mine] = binBase[bin0] + rank0; W.sortTag[mine] = (uint8_t)(bin0 | (copy << 6)); }
-    for (uint32_t k = 1; k < nseg; ++k) {
-        uint4 *e = W.stageEnt + 4 * (size_t)(extraAt + k - 1);
-        const uint32_t tag = e[0].y >> 24;
-        if (e[0].x == 0xffffffffu) break;
-        const uint32_t w = e[3].w;
-        W.sortRank[extraAt + k - 1] = binBase[tag & 63u] + (w & 0xffffffu);
-        W.sortTag[extraAt + k - 1] = (uint8_t)tag;
-    }
-    } // items
-}
-
-// Work items: the used 256-entry blocks of the queue slices (region A: segment 0 of every request, in queue order), then the
-// blocks of region B (further segments, densely packed); a fixed grid takes them in turn.
-__global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round)
+// Work items: the used 256-entry blocks of the queue slices (region A: segment 0 of every ray, in queue order), then the
+// blocks of region B (further segments, densely packed); a fixed grid takes them in turn.  The logic kernel left a rank inside
+// its (class, copy) and the class itself per entry; the classes' sizes are in the round's histogram.
+__global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round, const uint32_t slices)
 {
     __shared__ uint32_t base[RT_WF_SORT_BINS * RT_WF_SORT_COPIES];
     __shared__ uint32_t longWave[4];
+    uint32_t *ctl = W.ctl + (round % 3) * RT_WF_CTL_WORDS;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ uint32_t raysWave[4];
     {
-        const uint32_t c0 = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x], c1 = W.counts[(round % 3) * RT_WF_QSHARDS + 256 + threadIdx.x];
-        uint32_t m = max(c0, c1), n = c0 + c1;
+        const uint32_t c0 = ctl[RT_WF_CTL_COUNTS + threadIdx.x], c1 = ctl[RT_WF_CTL_COUNTS + 256 + threadIdx.x];
+        uint32_t m = max(c0, c1);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off, 64)); n += __shfl_xor(n, off, 64); }
-        if (lane == 0) { longWave[wave] = m; raysWave[wave] = n; }
+        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if (lane == 0) longWave[wave] = m;
     }
-    __syncthreads();
-    if (raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3] < W.appendRays) return; // the round was appended by wf_setup_kernel
     if (threadIdx.x < RT_WF_SORT_BINS) { // one wave: exclusive prefix over (bin, copy), bin-major
-        uint32_t h[RT_WF_SORT_COPIES], sum = 0;
-#pragma unroll
-        for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { h[c] = W.sortHist[c * RT_WF_SORT_BINS + threadIdx.x]; sum += h[c]; }
+        uint32_t sum = 0;
+        for (int c = 0; c < RT_WF_SORT_COPIES; ++c) sum += ctl[RT_WF_CTL_HIST + c * RT_WF_SORT_BINS + threadIdx.x];
         uint32_t incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1074,33 +1072,29 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
             if ((int)threadIdx.x >= off) incl += up;
         }
         uint32_t at = incl - sum;
-#pragma unroll
-        for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { base[threadIdx.x * RT_WF_SORT_COPIES + c] = at; at += h[c]; }
-        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) { // all entries are in [0, total)
-            W.sortTotal[0] = incl;
-            W.sortTotal[1] = (raysWave[0] + raysWave[1] + raysWave[2] + raysWave[3] >= W.regionRays) ? RT_WF_ORDER_REGION : RT_WF_ORDER_LENGTH;
-        }
+        for (int c = 0; c < RT_WF_SORT_COPIES; ++c) { base[threadIdx.x * RT_WF_SORT_COPIES + c] = at; at += ctl[RT_WF_CTL_HIST + c * RT_WF_SORT_BINS + threadIdx.x]; }
+        if (blockIdx.x == 0 && threadIdx.x == RT_WF_SORT_BINS - 1) ctl[RT_WF_CTL_TOTAL] = incl; // all entries are in [0, total)
     }
     __syncthreads();
     const uint32_t usedBlocks = (max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3])) + 255u) >> 8;
-    const uint32_t itemsA = RT_WF_QSHARDS * usedBlocks;
-    const uint32_t extra = min(W.sortExtra[0], W.extraCap); // the count runs past the capacity when region B filled up (wf_setup_kernel)
+    const uint32_t itemsA = 2u * slices * usedBlocks;
+    const uint32_t extra = min(ctl[RT_WF_CTL_EXTRA], W.extraCap); // the count runs past the capacity when region B filled up (wf_logic_kernel)
     const uint32_t itemsB = (extra + 255u) >> 8;
     for (uint32_t item = blockIdx.x; item < itemsA + itemsB; item += gridDim.x) {
         uint32_t mine = 0;
         bool valid = false;
         if (item < itemsA) {
-            const uint32_t shard = item % RT_WF_QSHARDS;
-            const uint32_t local = (item / RT_WF_QSHARDS) * 256 + threadIdx.x;
-            valid = local < W.counts[(round % 3) * RT_WF_QSHARDS + shard];
-            mine = shard * W.shardCap + local;
+            const uint32_t sl = item % (2u * slices);
+            const uint32_t local = (item / (2u * slices)) * 256 + threadIdx.x;
+            valid = local < slice_count(ctl, slices, sl);
+            mine = slice_first(W, slices, sl) + local;
         } else {
             const uint32_t local = (item - itemsA) * 256 + threadIdx.x;
             valid = local < extra;
             mine = 2u * W.capacity + local;
         }
         if (valid) {
-            // only the ORDER is written: the trace kernel gathers its 64-byte entries from the staging array through it
+            // only the ORDER is written: the trace kernel gathers its 64-byte entries through it
             const uint32_t rank = W.sortRank[mine];
             if (rank != 0xffffffffu) { // not an unused reservation
                 const uint32_t tag = W.sortTag[mine]; // bin | copy << 6
@@ -1139,7 +1133,7 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 #ifndef RT_WF_LEAN_STALL
 #define RT_WF_LEAN_STALL 64           // test once (lanes without room for another phase) x this exceeds the lanes still walking
 #endif
-__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round)
+__global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round, const RtRoundMode mode)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
     __shared__ uint32_t cellList[RT_WF_LEAN_LIST][256];                 // [entry][thread] packed cells cx | cy<<8 | cz<<16
@@ -1149,49 +1143,60 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     __shared__ uint32_t moreCount[4];
     static_assert(RT_WF_LEAN_LIST <= 16, "hit_key: 4 bits of cell order");
 
-    // entries [0, total) and -- in an appended round -- the extra segments in region B, which follow in 64-entry chunks
-    const uint32_t total = W.sortTotal[0];
-    const uint32_t order = W.sortTotal[1];
-    const bool appended = order == RT_WF_ORDER_APPENDED;
-    const uint32_t extra = appended ? min(W.sortExtra[0], W.extraCap) : 0u;
-    const uint32_t chunksA = (total + 63u) >> 6, chunksB = (extra + 63u) >> 6;
-    // Which 256 entries this workgroup takes.  Ordered by length: workgroup i takes block i, so the longest walks start first.
-    // Ordered by region: the hardware deals consecutive workgroups round-robin to the 8 XCDs (placement is a speed matter
-    // only, nothing depends on it), so workgroup i takes block (i % 8) * blocksPerXcd + i / 8 -- every XCD works its way
-    // through ONE contiguous eighth of the region-ordered entries and its L2 holds the one or two regions it is in.
-    const uint32_t blocksUsed = (chunksA + chunksB + 3u) >> 2;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (round < RT_WF_ROUND_LOG) W.roundLog[round] = (total + extra) | (appended ? 0x80000000u : 0u); // (bit 31: not sorted)
+    // Which 256 entries this workgroup takes.
+    //   ordered round:  block i of the sorted order, through sortedIdx -- the hardware dispatches workgroups in order, so the longest
+    //                   walks start first and a free slot always gets the longest work left;
+    //   other rounds:   the blocks of region B (further segments) first, then the 256-entry blocks of the queue slices, slice-minor
+    //                   (block b of every slice before block b + 1 of any: slices fill evenly).
+    // A planned frame's grid is sized from the same frame's previous rendering (rt_api.cpp); should it be too small the host is told
+    // and renders the frame again with the worst-case grid (a loop that strides over the rest measured 4 % slower).
+    const uint32_t *ctl = W.ctl + (round % 3) * RT_WF_CTL_WORDS;
+    const uint32_t par = round & 1;
+    const uint32_t extra = min(ctl[RT_WF_CTL_EXTRA], W.extraCap);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && round < RT_WF_ROUND_LOG) reinterpret_cast<uint32_t *>(W.roundLog + round)[2] = extra;
+    uint32_t mine = 0;
+    bool active = false;
+    if (mode.ordered) {
+        const uint32_t total = ctl[RT_WF_CTL_TOTAL];
+        const uint32_t blocksUsed = (total + 255u) >> 8;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && blocksUsed > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+        if (blockIdx.x >= blocksUsed) return; // whole workgroup beyond the entries
+        const uint32_t at = blockIdx.x * 256 + threadIdx.x;
+        active = at < total;
+        if (active) mine = W.sortedIdx[at];
+    } else {
+        const uint32_t blocksB = (extra + 255u) >> 8, perRow = 2u * mode.slices;
+        const uint32_t rows = gridDim.x > blocksB ? (gridDim.x - blocksB) / perRow : 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && rows == 0u) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+        if (blockIdx.x < blocksB) {
+            const uint32_t local = blockIdx.x * 256 + threadIdx.x;
+            active = local < extra;
+            mine = 2u * W.capacity + local;
+        } else {
+            const uint32_t item = blockIdx.x - blocksB;
+            const uint32_t sl = item % perRow, row = item / perRow;
+            if (row >= rows) return; // (an incomplete last row of the grid)
+            const uint32_t count = slice_count(ctl, mode.slices, sl);
+            if (threadIdx.x == 0 && row + 1 == rows && count > rows * 256u) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+            if (row * 256u >= count) return; // this slice is shorter
+            const uint32_t local = row * 256 + threadIdx.x;
+            active = local < count;
+            mine = slice_first(W, mode.slices, sl) + local;
+        }
     }
-    const uint32_t perXcd = (blocksUsed + 7u) >> 3;
-    const uint32_t slots = (order == RT_WF_ORDER_REGION) ? 8u * perXcd : blocksUsed; // work items the grid has to cover
-    if (blockIdx.x == 0 && threadIdx.x == 0 && slots > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
-    if (blockIdx.x >= slots) return; // whole workgroup beyond the entries
     for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // One workgroup per 256 sorted entries, dispatched by the hardware in order: the longest walks start first and a free
-    // slot always gets the longest work left.  (Fixed grids whose waves stride over the array, or take chunks from a shared
-    // cursor, were 23 % and 11 % slower; the price of this grid is ~0.35 us per 1000 workgroups that find nothing to do.)
-    // (a planned frame's grid is sized from the same frame's previous rendering, rt_api.cpp; should it be too small the host is
-    // told and renders the frame again with the worst-case grid -- a loop that strides over the rest measured 4 % slower)
-    for (uint32_t slot = blockIdx.x, once = 0; once < 1u; ++once) {
-    const uint32_t blockAt = (order == RT_WF_ORDER_REGION) ? (slot & 7u) * perXcd + (slot >> 3) : slot;
-    const uint32_t chunk = blockAt * 4 + wave;
-    if (chunk >= chunksA + chunksB) break;
-    const bool inB = chunk >= chunksA;
-    const uint32_t mine = inB ? 2u * W.capacity + (chunk - chunksA) * 64 + lane : chunk * 64 + lane;
-    bool active = inB ? (chunk - chunksA) * 64 + lane < extra : mine < total;
+    for (uint32_t once = 0; once < 1u; ++once) {
     uint32_t q = 0, excluded = RT_NONE, cell = 0, endCell = 0xffffffffu, seg = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
     if (active) {
-        // a sorted round: position -> staging entry through sortedIdx; an appended round: the entry sits at the position itself
-        const uint4 *e = appended ? W.sortedEnt + 4 * (size_t)mine : W.stageEnt + 4 * (size_t)W.sortedIdx[mine];
+        const uint4 *e = W.ent[par] + 4 * (size_t)mine;
         const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
         q = c0.x; cell = c0.y & 0xffffffu; endCell = c0.z; excluded = c0.w;
-        if (q == 0xffffffffu) active = false; // an unused reservation of an appended round
+        if (q == 0xffffffffu) active = false; // an unused reservation in region B
         dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
         o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
         d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
@@ -1434,7 +1439,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 if (mineN) {
                     const unsigned long long key = keys[lane];
                     if (key != ~0ull) { // this segment's hit: the ray's answer is that of its lowest segment with one
-                        atomicMin(&W.hitKey[q], ((unsigned long long)seg << 32) | (key & (unsigned long long)(2u * RT_PAIR_LIMIT - 1u)));
+                        atomicMin(&W.hitKey[par][q], ((unsigned long long)seg << 32) | (key & (unsigned long long)(2u * RT_PAIR_LIMIT - 1u)));
                         active = false;
                         walkEnded = true;
                     }
@@ -1497,7 +1502,7 @@ __global__ __launch_bounds__(256) void wf_accum_kernel(const RtDevScene S, const
 __global__ __launch_bounds__(256) void wf_status_kernel(const RtWavefront W, const uint32_t round)
 {
     __shared__ uint32_t part[4];
-    uint32_t n = W.counts[(round % 3) * RT_WF_QSHARDS + threadIdx.x]; // RT_WF_SHARDS == 256 main slices
+    uint32_t n = W.ctl[(round % 3) * RT_WF_CTL_WORDS + RT_WF_CTL_COUNTS + threadIdx.x]; // RT_WF_SHARDS == 256 main slices
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
@@ -1517,26 +1522,31 @@ extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefr
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+static bool mode_ok(const RtRoundMode &m) { return m.slices >= 1u && m.slices <= RT_WF_SHARDS && (m.slices & (m.slices - 1u)) == 0u && m.segLen >= 1u; }
+
+// slicesIn: the queue slices of the round this launch consumes; next: the layout of the round it spawns (next.slices <= slicesIn)
+extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, uint32_t slicesIn, const RtRoundMode *next, hipStream_t stream)
 {
     if (blocks % (RT_WF_SHARDS / 4) != 0) return hipErrorInvalidValue; // a whole number of waves per queue slice (wf_logic_kernel)
-    if (round == 0u) hipLaunchKernelGGL(wf_logic_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
-    else hipLaunchKernelGGL(wf_logic_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    if (!mode_ok(*next) || slicesIn < next->slices || slicesIn > RT_WF_SHARDS || (slicesIn & (slicesIn - 1u)) != 0u) return hipErrorInvalidValue;
+    if (round == 0u) hipLaunchKernelGGL(wf_logic_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
+    else hipLaunchKernelGGL(wf_logic_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
     return hipGetLastError();
 }
 
-// setup + scatter of one round's requests: fixed grids, the kernels stride over the blocks that are in use
-extern "C" hipError_t rtw_launch_sort(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, int appendedPlan, hipStream_t stream)
+// an ordered round: ranks -> positions (fixed grid, the kernel strides over the blocks that are in use)
+extern "C" hipError_t rtw_launch_scatter(const RtWavefront *wf, uint32_t round, uint32_t blocks, const RtRoundMode *mode, hipStream_t stream)
 {
-    hipLaunchKernelGGL(wf_setup_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, (uint32_t)(appendedPlan ? 1 : 0));
-    if (!appendedPlan) hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round);
+    if (!mode_ok(*mode)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wf_scatter_kernel, dim3(blocks), dim3(256), 0, stream, *wf, round, mode->slices);
     return hipGetLastError();
 }
 
-// one workgroup per 256 sorted entries (grid sized for the worst case; surplus workgroups exit at once)
-extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, hipStream_t stream)
+// one workgroup per 256 entries (a watched frame's grid is sized for the worst case; surplus workgroups exit at once)
+extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, const RtRoundMode *mode, hipStream_t stream)
 {
-    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round);
+    if (!mode_ok(*mode)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, *mode);
     return hipGetLastError();
 }
 

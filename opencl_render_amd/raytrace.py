@@ -66,7 +66,7 @@ RESIDENT_SYMBOLS = [
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipDetileStore", "rtHipDeviceAlloc", "rtHipDeviceFree", "rtHipDeviceCopy", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
-    "rtHipDeviceKat", "rtHipTestHashBytes",
+    "rtHipDeviceKat", "rtHipTune", "rtHipTestHashBytes",
     "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
 ]
 
@@ -150,12 +150,42 @@ def lib() -> C.CDLL:
     L.rtHipBuildCameraListDevice.argtypes = [C.c_int, u32, u32, vp, vp, vp, vp, f32, u32, u32, vp, vp,
                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_double)]
     L.rtHipDeviceKat.argtypes = [C.c_int, C.c_int, u32, vp, u32, vp, u32, vp]
+    L.rtHipTune.argtypes = [C.c_char_p, C.c_double]
     L.rtHipTestHashBytes.restype = u64
     L.rtHipTestHashBytes.argtypes = [vp, u64]
     L.rtHipFree.argtypes = [vp]
     L.rtHipFree.restype = None
     _lib = L
     return L
+
+
+# The library itself reads no environment variables.  Sweep scripts and tests steer it through the RT_* variables of THIS
+# process: they are translated into rtHipTune() calls whenever a scene is about to be built.
+_ENV_KEYS = {
+    "RT_HIP_STAGE_MB": "stage_mb", "RT_WF_EXTRA_FACTOR": "extra_factor", "RT_WF_STATE_MB": "state_mb", "RT_WF_GROUPS": "groups",
+    "RT_WF_LOOKAHEAD": "lookahead", "RT_WF_FAST_QUOTIENT": "fast_quotient", "RT_WF_SPIN_LIMIT": "spin_limit",
+    "RT_WF_APPEND_RAYS": "append_rays", "RT_WF_SLICE_RAYS": "slice_rays", "RT_WF_SMALL_SLICES": "small_slices",
+    "RT_WF_BLOCKING": "blocking", "RT_WF_BATCH_PLAN": "batch_plan", "RT_WF_PLAN_ROUNDS": "plan_rounds", "RT_HIP_PIPELINE": "pipeline",
+    "RT_HIP_TIMING": "timing", "RT_HIP_VIRTUAL_DEVICES": "virtual_devices", "RT_HIP_CACHE": "cache",
+}
+
+
+def tune(key: str, value: float) -> None:
+    if lib().rtHipTune(key.encode(), float(value)) != 0:
+        raise ValueError(last_error())
+
+
+def apply_env_tuning() -> None:
+    """rtHipTune("reset") followed by one call per RT_* variable that is set in os.environ."""
+    tune("reset", 0)
+    for var, key in _ENV_KEYS.items():
+        if var in os.environ:
+            tune(key, float(os.environ[var]))
+    for var, key, n in (("RT_WF_SEG", "seg", 5), ("RT_WF_SEG_RAYS", "seg_rays", 4)):
+        for i, v in enumerate([x for x in os.environ.get(var, "").split(",") if x][:n]):
+            tune(f"{key}{i}", float(v))
+    if os.environ.get("RT_WF_PLAN_GRID") == "tiny":
+        tune("plan_grid_tiny", 1)
 
 
 def last_error() -> str:
@@ -257,6 +287,7 @@ def build_lists(sc: Scene, threads: int = 0) -> Scene:
 def raytrace_all(computation_type: int, sc: Scene):
     """RaytraceAll through the drop-in ABI.  Returns (ok, R, G, B) with [H,W] uint16 planes."""
     L = lib()
+    apply_env_tuning()
     r = np.zeros(sc.pixels, np.uint16)
     g = np.zeros(sc.pixels, np.uint16)
     b = np.zeros(sc.pixels, np.uint16)
@@ -326,6 +357,7 @@ class ResidentScene:
 
     def __init__(self, sc: Scene, device: int = 0, tiles: Optional[Sequence[int]] = None):
         L = lib()
+        apply_env_tuning()
         self.scene = sc
         self.device = device
         self.tiles = None if tiles is None else np.ascontiguousarray(tiles, np.uint32)

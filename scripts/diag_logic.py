@@ -9,8 +9,9 @@ rs = R.ResidentScene(sc, 0)
 rs.render(); rs.sync(); rs.debug_counters(True)
 rs.render(); rs.sync()
 v = rs.debug_counters(True)
-names = ["start -> state words here", "-> ring / resolved hit here", "-> material id here", "-> material + normal", "-> texels, draws, spawns",
-         "-> machine left", "-> look-ahead ring entry read", "-> appended, stores issued"]
-tot = sum(v)
-for n, x in zip(names, v): print(f"{n:34s} {x / 1e6:10.1f} Mclk  {100.0 * x / max(tot, 1):5.1f} %")
+names = ["start -> state machine left", "-> look-ahead ray picked", "-> queue positions (atomics)", "-> trace entries written", "-> classes + ranks (ordered round)",
+         "-> end of the chunk"]
+tot = v[7]
+for n, x in zip(names, v[:6]): print(f"{n:38s} {x / 1e6:10.1f} Mclk  {100.0 * x / max(tot, 1):5.1f} %   {x / max(v[6], 1):9.0f} clk per chunk")
+print(f"chunks {v[6]}, {tot / max(v[6], 1):.0f} clk per chunk")
 rs.close()

@@ -249,17 +249,18 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
 
 
 @pytest.mark.parametrize("env", [
-    {"RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
-    {"RT_WF_SEG": "40,24,12,8"},                              # finer still for small rounds
-    {"RT_WF_SEG": "4096,4096,4096,4096"},                       # never cut
+    {"RT_WF_SEG": "16,16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
+    {"RT_WF_SEG": "40,24,12,8,8"},                            # finer still for small rounds
+    {"RT_WF_SEG": "4096,4096,4096,4096,4096"},                  # never cut
     {"RT_WF_APPEND_RAYS": "0"},                            # every round goes through the counting sort
-    {"RT_WF_APPEND_RAYS": "4000000000", "RT_WF_SEG": "24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1"},  # no round does, all rays cut
+    {"RT_WF_APPEND_RAYS": "4000000000", "RT_WF_SEG": "24,24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1,1"},  # no round does, all rays cut
     {"RT_WF_LOOKAHEAD": "0"},                              # one ray in flight per path
     {"RT_WF_GROUPS": "3"},                                 # three concurrent tile groups per instance
-    {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1", "RT_WF_LOOKAHEAD": "0"},
-    {"RT_WF_REGION_RAYS": "1", "RT_WF_APPEND_RAYS": "0"},   # every round cut at region boundaries and traced region by region
-    {"RT_WF_REGION_RAYS": "1", "RT_WF_APPEND_RAYS": "0", "RT_WF_EXTRA_FACTOR": "1", "RT_WF_LOOKAHEAD": "0"},  # ... with a region B that overflows
-    {"RT_WF_REGION_RAYS": "4000000000"},                   # never
+    {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1,1", "RT_WF_LOOKAHEAD": "0"},
+    {"RT_WF_SLICE_RAYS": "0"},                              # every round spreads its entries over all 256 queue slices per kind
+    {"RT_WF_SLICE_RAYS": "4000000000", "RT_WF_SMALL_SLICES": "1", "RT_WF_APPEND_RAYS": "4000000000"},  # one slice per kind from round 1 on, nothing ordered
+    {"RT_WF_SLICE_RAYS": "20000", "RT_WF_SMALL_SLICES": "4", "RT_WF_APPEND_RAYS": "0", "RT_WF_SEG": "24,24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1,1"},  # slices merge mid-frame, every round ordered and cut
+    {"RT_WF_BLOCKING": "1"},                                # every batch of every frame watched
     {"RT_WF_FAST_QUOTIENT": "0"},                          # every wave divides the long way (the default picks per wave: test_kat_gpu.py)
 ])
 def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
@@ -274,9 +275,16 @@ def test_pipeline_modes_are_invisible_in_the_planes(monkeypatch, env):
         assert_planes(R.render_resident(sc, 0), want, f"{name} with {env}")
     sc = S.make_soup(640, 360, 60_000, 0.012, seed=77, samples=2)
     R.build_lists(sc)
-    got = R.render_resident(sc, 0)
     want = O.oracle_render(sc, threads=os.cpu_count() or 1)
-    assert_planes(got, want, f"640x360 soup with {env}")
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()   # watched frame (guessed layouts)
+        assert_planes(rs.readback(), want, f"640x360 soup with {env}, watched frame")
+        rs.render()   # planned frame (layouts from the plan)
+        assert not rs.finish()
+        assert_planes(rs.readback(), want, f"640x360 soup with {env}, planned frame")
+    finally:
+        rs.close()
 
 
 def test_dropin_all_gpus_mode_threads_and_tile_deal(monkeypatch):
@@ -301,11 +309,11 @@ def test_dropin_all_gpus_mode_threads_and_tile_deal(monkeypatch):
 def test_region_b_overflow_keeps_rays_whole(monkeypatch, append_rays):
     """Every ray of a full-coverage 640x360 frame is cut into segments of ~8 cell visits: the extra segments of the first
     rounds (several million) do not fit region B of the entry arrays (2 x capacity = 524 288 entries here), so hundreds of
-    workgroups find it full while others still fit.  A reservation that does not fit must leave its rays whole and must
+    waves find it full while others still fit.  A reservation that does not fit must leave its rays whole and must
     not disturb anybody else's slots (the add is never undone, readers clamp the count, the straddling range is marked
-    empty: wf_setup_kernel)."""
-    monkeypatch.setenv("RT_WF_SEG", "8,8,8,8")
-    monkeypatch.setenv("RT_WF_SEG_RAYS", "1,1,1")
+    empty: wf_logic_kernel)."""
+    monkeypatch.setenv("RT_WF_SEG", "8,8,8,8,8")
+    monkeypatch.setenv("RT_WF_SEG_RAYS", "1,1,1,1")
     monkeypatch.setenv("RT_WF_APPEND_RAYS", append_rays)
     sc = S.make_soup(640, 360, 40_000, 0.06, seed=31, samples=1)
     R.build_lists(sc)
@@ -440,26 +448,6 @@ def test_planned_trace_grid_that_is_too_small_is_noticed(monkeypatch):
         rs.render()
         assert rs.finish() is True
         assert_planes(rs.readback(), want, "frame redone after a too-small trace grid")
-    finally:
-        rs.close()
-
-
-def test_planned_round_that_has_to_be_sorted_after_all_is_noticed(monkeypatch):
-    """A planned frame issues no scatter launch for a round whose entries were appended (not sorted) when the frame was last
-    rendered.  Should such a round be big enough for the counting sort after all (forced here: the plan claims every round was
-    appended, and RT_WF_APPEND_RAYS=0 sorts them all), wf_setup_kernel tells the host and finish() renders the frame again."""
-    monkeypatch.setenv("RT_WF_PLAN_SORT", "skip")
-    monkeypatch.setenv("RT_WF_APPEND_RAYS", "0")
-    sc = S.make_soup(320, 200, 20_000, 0.03, seed=43, samples=1)
-    R.build_lists(sc)
-    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
-    rs = R.ResidentScene(sc, 0)
-    try:
-        rs.render()
-        assert not rs.finish()
-        rs.render()
-        assert rs.finish() is True
-        assert_planes(rs.readback(), want, "frame redone after a round that had to be sorted")
     finally:
         rs.close()
 
