@@ -379,7 +379,7 @@ int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint in
  * down, make them redo themselves or fail); every tuning value and every fault injector of the tests is set here, process-wide,
  * and applies to scenes built afterwards.  Keys (rt_api.cpp, struct Tuning): "reset" (all defaults), "stage_mb", "extra_factor",
  * "state_mb", "groups", "lookahead", "seg0".."seg4", "seg_rays0".."seg_rays3", "fast_quotient", "spin_limit", "append_rays",
- * "slice_rays", "small_slices", "blocking", "batch_plan", "pipeline", "timing", "cache", and the test hooks "plan_rounds",
+ * "slice_rays", "small_slices", "group_rays", "blocking", "batch_plan", "pipeline", "timing", "cache", and the test hooks "plan_rounds",
  * "plan_grid_tiny", "virtual_devices".  Returns 0, -1 for an unknown key. */
 int rtHipTune(const char *key, double value);
 

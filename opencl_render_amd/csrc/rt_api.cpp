@@ -72,7 +72,6 @@ int fail(const char *fmt, ...)
 // afterwards.
 struct Tuning {
     uint32_t stageMb = 32;          // size of each of the two pinned staging buffers of an upload
-    uint32_t extraFactor = 6;       // region B of the entry arrays, in units of the path capacity
     uint64_t stateMb = 0;           // path-state budget per sample batch (0 = 24 GB, never more than a third of free memory); tests force several batches
     uint32_t groups = 1;            // concurrent tile groups per instance (measured: no gain once rays are cut into segments)
     uint32_t lookAhead = 1;         // 0: one ray in flight per path
@@ -80,9 +79,11 @@ struct Tuning {
     uint32_t segRays[4] = { 700000u, 300000u, 100000u, 30000u };
     uint32_t fastQuotient = 1;
     uint32_t spinLimit = 16384;     // a ray makes at most 766 cell visits = 154 walk phases; lowered by the test of the guard's error path
-    uint32_t appendRays = 150000;   // rounds with fewer rays are traced in queue order, unsorted
-    uint32_t sliceRays = 150000;    // rounds with fewer rays use smallSlices queue slices per kind instead of RT_WF_SHARDS
+    uint32_t appendRays = 300000;   // rounds with fewer rays are not ordered: the trace kernel plans and cuts their rays itself (RtRoundMode)
+    uint32_t sliceRays = 0;         // rounds with fewer rays use smallSlices queue slices per kind instead of RT_WF_SHARDS (off: a round's appends want
+                                    // many counters -- 16 slices cost the logic kernel of a 58 k-ray round 17 us -- and the trace kernel packs its pieces anyway)
     uint32_t smallSlices = 16;
+    uint32_t groupRays = 0;         // rays per workgroup of the trace kernel in rounds that are not ordered (0 = by segment length)
     uint32_t blocking = 0;          // 1: every frame watches its queue (no launch plan)
     uint32_t planRounds = 0;        // test hook: planned frames issue at most this many rounds, so that the too-short-plan path runs
     uint32_t planGridTiny = 0;      // test hook: planned trace grids of one workgroup, so that the too-small-grid path runs
@@ -212,9 +213,7 @@ struct rtHipScene {
         // launch plan (render_wavefront): what the last discovery frame needed
         uint32_t roundsNeeded = 0;
         // per round: rays (entries in region A), the longest queue slice, entries in region B -- the maximum over the watched batches
-        // longest = longest queue slice x slices in use (what one slice per kind would hold at most); it and extra depend on the layout the
-        // round had when it was logged: `slices` (the fewest of the batches), `segLen` (the finest)
-        struct RoundPlan { uint32_t rays = 0, longest = 0, extra = 0, slices = RT_WF_SHARDS, segLen = 4096; };
+        struct RoundPlan { uint32_t rays = 0; };
         uint4 *hostLog = nullptr;       // pinned + mapped: RtWavefront::roundLog, written by the kernels, read by the host after a sync
         RoundPlan plan[RT_WF_ROUND_LOG], planNext[RT_WF_ROUND_LOG];
         std::vector<RtRoundMode> modes; // how the rounds of the batch being issued are laid out (modes[r] is decided when logic(r-1) is launched)
@@ -415,6 +414,20 @@ int build_grid(rtHipScene *sc, const rtHipSceneDesc *d)
     for (int w = 0; w < 3; ++w)
         for (int i = 0; i <= RT_GRID_DIV; ++i) planes[w * (RT_GRID_DIV + 1) + i] = d->boxMin[i].s[w];
     if (sc->upload(planes.data(), planes.size(), &D.boxMin, "boxMin")) return -1;
+    { // the cell estimate table of rt_device.h (cellLut)
+        std::vector<uint8_t> lut(3 * 256);
+        for (int w = 0; w < 3; ++w) {
+            const float *pw = planes.data() + w * (RT_GRID_DIV + 1);
+            const float lo = pw[0], step = (pw[RT_GRID_DIV] - pw[0]) / 256.f;
+            int c = 0;
+            for (int i = 0; i < 256; ++i) {
+                const float x = lo + ((float)i + 0.5f) * step;
+                while (c < RT_GRID_DIV - 1 && pw[c + 1] < x) ++c; // (planes ascend: the cell index only ever grows with i)
+                lut[w * 256 + i] = (uint8_t)c;
+            }
+        }
+        if (sc->upload(lut.data(), lut.size(), &D.cellLut, "cellLut")) return -1;
+    }
     D.planesTame = 1u;
     for (float pl : planes) {
         const float m = std::fabs(pl);
@@ -537,10 +550,9 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     HIP_OK(hipGetDeviceProperties(&prop, sc->device));
     const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
-    const uint32_t extraFactor = std::min<uint32_t>(std::max<uint32_t>(T.extraFactor, 1u), 16u);
-    // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot, primary hit; per queue entry (two per path and round
-    // parity): path id + answer; per entry (2 + extraFactor per path and parity): the 64-byte entry; per entry: rank, class, sorted position
-    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 2 * 2 * (4 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 4 + 2 + 4) + 16;
+    // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot, primary hit, finished colour; per queue entry (two per
+    // path): path id, answer and the 64-byte entry per round parity, rank, class, sorted position
+    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 16 + 2 * (2 * (4 + 8 + 64) + 4 + 2 + 4);
     // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
     // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
     uint64_t budget = 24ull << 30;
@@ -577,10 +589,7 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         Wf.shardCap = (uint32_t)shardCap;
         Wf.lookAhead = T.lookAhead ? 1u : 0u;
         const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path
-        const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the further segments of cut rays (a wave that finds it full leaves its rays whole)
-        const uint64_t ecap = qcap + extraCap;
-        if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
-        Wf.extraCap = (uint32_t)extraCap;
+        const uint64_t ecap = qcap;
         Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
         if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
             sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
@@ -604,7 +613,7 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         Wf.fastQuotient = T.fastQuotient ? 1u : 0u;
         // fixed grids: the kernels stride over the work that is really there (queues are sized for the worst case)
         G.queueBlocks = std::min<uint32_t>(cus * 16, (uint32_t)(qcap / 256)); // scatter: two generations of 8 resident workgroups per CU
-        G.traceBlocks = (uint32_t)(ecap / 256); // trace, worst case: one workgroup per 256 entries; surplus groups exit at once
+        G.traceBlocks = (uint32_t)(ecap / 256); // trace of an ordered round, worst case: one workgroup per 256 entries; surplus groups exit at once
         // (a whole number of waves per queue slice: wf_logic_kernel keeps a wave in one slice)
         G.logicBlocks = std::min<uint32_t>(cus * 8, (uint32_t)((cap + 255) / 256));
         G.logicBlocks = std::max<uint32_t>(RT_WF_SHARDS / 4, (G.logicBlocks + RT_WF_SHARDS / 4 - 1) / (RT_WF_SHARDS / 4) * (RT_WF_SHARDS / 4));
@@ -674,17 +683,6 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
 
 // How a round with `rays` rays is laid out (RtRoundMode, rt_device.h): big rounds are ordered by predicted walk length and spread
 // their appends over all queue slices, small ones are cut into segments and keep their entries dense.
-#define RT_WF_MAXSEG_HOST 12 // RT_WF_MAXSEG of rt_wavefront.hip: segments a ray is cut into at most
-
-// Entries in region B if a round logged with `extra` further segments at `segFrom` visits per segment were cut at `segTo` instead: a
-// cut c times finer makes at most c segments of one (a coarser one never more).
-uint64_t extra_bound(uint64_t rays, uint64_t extra, uint32_t segFrom, uint32_t segTo)
-{
-    if (segTo >= segFrom) return extra;
-    const uint64_t c = ((uint64_t)segFrom + segTo - 1) / segTo;
-    return std::min<uint64_t>(rays * (RT_WF_MAXSEG_HOST - 1), c * extra + (c - 1) * rays);
-}
-
 RtRoundMode mode_for(const Tuning &T, uint64_t rays, uint32_t slicesBefore)
 {
     RtRoundMode m;
@@ -695,6 +693,10 @@ RtRoundMode mode_for(const Tuning &T, uint64_t rays, uint32_t slicesBefore)
     if (small < 1u || small > RT_WF_SHARDS || (small & (small - 1u))) small = 16u;
     m.slices = rays >= T.sliceRays ? (uint32_t)RT_WF_SHARDS : small;
     if (m.slices > slicesBefore) m.slices = slicesBefore; // a slice holds at most the paths of its shards: slices only ever merge
+    // rays per workgroup of the trace kernel: about 256 lanes / the segments a ray of this round is expected to be cut into ...
+    // ... and few enough workgroups for all of them to run at once (5 per CU): the round lasts as long as its slowest workgroup
+    m.groupRays = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(16, ((rays + 1099) / 1100 + 15) / 16 * 16));
+    if (T.groupRays >= 1u && T.groupRays <= 128u) m.groupRays = T.groupRays;
     return m;
 }
 
@@ -757,26 +759,19 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
         return G.modes[r];
     };
     auto trace_blocks = [&](rtHipScene::Group &G, uint32_t r, const RtRoundMode &m) -> uint32_t {
-        if (!planned || r >= RT_WF_ROUND_LOG) return G.traceBlocks;
+        // worst case: every queue slot in use -- an ordered round takes 256 entries per workgroup, any other mode.groupRays rays of
+        // one queue slice (every slice's last piece may be a partial one)
+        const uint64_t worst = m.ordered ? G.traceBlocks : 2ull * G.wf.capacity / m.groupRays + 2ull * m.slices;
+        if (!planned || r >= RT_WF_ROUND_LOG) return (uint32_t)std::min<uint64_t>(worst, 0x7fffffffu);
         if (T.planGridTiny) return 1;
-        // the same frame gave this many entries last time: a tenth more plus a few, never more than the worst case
-        // (a queue slice and region B are as long as the round's layout makes them; logged under another layout they are bounded:
-        // merging k slices gives at most k times the longest, a cut c times finer at most c segments where there was one)
-        const rtHipScene::Group::RoundPlan &P = G.plan[r];
-        const uint64_t longest = ((uint64_t)P.longest + std::min(m.slices, P.slices) - 1) / std::min(m.slices, P.slices);
-        const uint64_t extra = std::min<uint64_t>(extra_bound(P.rays, P.extra, P.segLen, m.segLen), G.wf.extraCap);
-        uint64_t want;
-        if (m.ordered) want = ((P.rays + extra) * 11 / 10 + 255) / 256 + 8;
-        else {
-            const uint64_t rowsMax = (uint64_t)G.wf.capacity / m.slices / 256;
-            const uint64_t rows = std::min<uint64_t>(rowsMax, (longest * 11 / 10 + 255) / 256 + 1);
-            want = (extra ? (extra * 11 / 10 + 255) / 256 + 2 : 0) + 2ull * m.slices * std::max<uint64_t>(rows, 1);
-        }
-        return (uint32_t)std::min<uint64_t>(G.traceBlocks, std::max<uint64_t>(want, 1));
+        // the same frame gave this many rays last time: a tenth more plus a few, never more than the worst case
+        const uint64_t rays = G.plan[r].rays;
+        const uint64_t want = m.ordered ? (rays * 11 / 10 + 255) / 256 + 8 : (rays * 11 / 10 + m.groupRays - 1) / m.groupRays + 2ull * m.slices + 8;
+        return (uint32_t)std::max<uint64_t>(std::min<uint64_t>(want, worst), 1);
     };
     auto issue_round = [&](rtHipScene::Group &G, hipStream_t on) -> int {
         const uint32_t r = G.rounds;
-        const RtRoundMode mode = r > 0 ? round_mode(G, r) : RtRoundMode{ 0u, 4096u, (uint32_t)RT_WF_SHARDS };
+        const RtRoundMode mode = r > 0 ? round_mode(G, r) : RtRoundMode{ 0u, 4096u, 64u, (uint32_t)RT_WF_SHARDS };
         if (r > 0) { // the entries appended by logic(r-1): order them if the round is an ordered one, then walk the grid
             if (mode.ordered) HIP_OK(stage(4, on, [&] { return rtw_launch_scatter(&G.wf, r, G.queueBlocks, &mode, on); }));
             HIP_OK(stage(2, on, [&] { return rtw_launch_trace(&G.dev, &G.wf, r, trace_blocks(G, r, mode), &mode, on); }));
@@ -847,15 +842,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
                 if (G.rounds > RT_WF_ROUND_LOG) needed = G.rounds;
                 G.roundsNeeded = std::max(G.roundsNeeded, needed);
                 for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) {
-                    // the maximum over the watched batches, in terms of the finest layout any of them had
-                    rtHipScene::Group::RoundPlan &N = G.planNext[r];
-                    const RtRoundMode m = r < G.modes.size() ? G.modes[r] : RtRoundMode{ 0u, 4096u, (uint32_t)RT_WF_SHARDS };
-                    const uint32_t seg = std::min(N.segLen, m.segLen);
-                    N.extra = (uint32_t)std::min<uint64_t>(0xffffffffu, std::max(extra_bound(N.rays, N.extra, N.segLen, seg), extra_bound(log[r].x, log[r].z, m.segLen, seg)));
-                    N.segLen = seg;
-                    N.rays = std::max(N.rays, log[r].x);
-                    N.longest = std::max(N.longest, log[r].y * m.slices);
-                    N.slices = std::min(N.slices, m.slices);
+                    G.planNext[r].rays = std::max(G.planNext[r].rays, log[r].x); // the maximum over the watched batches
                 }
             } else anyPlannedBatch = true;
             rounds = std::max<uint64_t>(rounds, G.rounds);
@@ -875,7 +862,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
                 need = std::max(need, G.roundsNeeded);
                 for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) {
                     G.plan[r] = G.planNext[r];
-                    G.plan[r].rays += G.plan[r].rays / 10; G.plan[r].longest += G.plan[r].longest / 10 + 8 * G.plan[r].slices; G.plan[r].extra += G.plan[r].extra / 10;
+                    G.plan[r].rays += G.plan[r].rays / 10;
                 }
             }
             planRounds = need + 1; // (one spare round: a later batch's deepest path may go one bounce further)
@@ -926,15 +913,6 @@ int frame_finish(rtHipScene *sc, hipStream_t st, int *redone)
         G.hostStatus[RT_WF_STATUS_WAITING] = 0u;
     }
     if (waiting == 0) {
-        // a complete planned frame of one batch logged its rounds under the layouts the plan implies: the plan's sizes become exact
-        // (they were bounds where the watched frame had guessed another layout)
-        if (sc->dev.sampleCount <= sc->samplesPerBatch)
-            for (auto &G : sc->groups)
-                for (uint32_t r = 1; r < std::min<uint32_t>((uint32_t)G.modes.size(), std::min<uint32_t>(G.rounds, RT_WF_ROUND_LOG)); ++r) {
-                    const uint4 l = G.hostLog[r];
-                    G.plan[r].rays = l.x; G.plan[r].longest = l.y * G.modes[r].slices; G.plan[r].extra = l.z;
-                    G.plan[r].slices = G.modes[r].slices; G.plan[r].segLen = G.modes[r].segLen;
-                }
         return 0;
     }
     if (redone) *redone = 1;
@@ -1356,11 +1334,11 @@ int rtHipTune(const char *key, double value)
     const uint32_t u = value < 0 ? 0u : (value > 4294967295.0 ? 0xffffffffu : (uint32_t)value);
     if (k == "reset") { T = Tuning(); return 0; }
     struct { const char *name; uint32_t *field; } table[] = {
-        { "stage_mb", &T.stageMb }, { "extra_factor", &T.extraFactor }, { "groups", &T.groups }, { "lookahead", &T.lookAhead },
+        { "stage_mb", &T.stageMb }, { "groups", &T.groups }, { "lookahead", &T.lookAhead },
         { "seg0", &T.segLen[0] }, { "seg1", &T.segLen[1] }, { "seg2", &T.segLen[2] }, { "seg3", &T.segLen[3] }, { "seg4", &T.segLen[4] },
         { "seg_rays0", &T.segRays[0] }, { "seg_rays1", &T.segRays[1] }, { "seg_rays2", &T.segRays[2] }, { "seg_rays3", &T.segRays[3] },
         { "fast_quotient", &T.fastQuotient }, { "spin_limit", &T.spinLimit }, { "append_rays", &T.appendRays }, { "slice_rays", &T.sliceRays },
-        { "small_slices", &T.smallSlices }, { "blocking", &T.blocking }, { "plan_rounds", &T.planRounds }, { "plan_grid_tiny", &T.planGridTiny },
+        { "small_slices", &T.smallSlices }, { "group_rays", &T.groupRays }, { "blocking", &T.blocking }, { "plan_rounds", &T.planRounds }, { "plan_grid_tiny", &T.planGridTiny },
         { "pipeline", &T.pipeline }, { "timing", &T.timing }, { "virtual_devices", &T.virtualDevices }, { "cache", &T.cache }, { "batch_plan", &T.batchPlan },
     };
     if (k == "state_mb") { T.stateMb = (uint64_t)(value < 0 ? 0 : value); return 0; }

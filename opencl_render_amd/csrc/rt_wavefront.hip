@@ -270,20 +270,23 @@ __global__ __launch_bounds__(256) void wf_primary_kernel(const RtDevScene S, con
 // head (:387-398).  So the state of the walk after all crossings with T <= tau is, per axis, simply the NUMBER of such
 // crossings -- it can be computed without walking (a plane search plus two exact divides per axis), for any tau.  A long
 // ray is therefore cut into up to RT_WF_MAXSEG SEGMENTS at parameters tau_k: segment k starts in the state at tau_k and ends
-// when it has visited the start cell of segment k+1 (the existing end-cell rule, :380).  Segments are traced as independent
-// entries; the ray's answer is the hit of its lowest segment that has one (atomicMin on hitKey), exactly the first cell
-// with a hit in path order.  Segments after a hit are wasted work; the chain per entry is ~8x shorter.
+// when it has visited the start cell of segment k+1 (the existing end-cell rule, :380).  Segments are traced by different
+// lanes; the ray's answer is the hit of its lowest segment that has one (atomicMin on hitKey), exactly the first cell
+// with a hit in path order.  Segments after a hit are wasted work; the chain per lane is ~8x shorter.
 //
-// The kernel that spawns a ray (wf_logic_kernel) writes its entries itself: the DDA start state is computed once, there,
-// where the ray is in registers -- a separate set-up kernel between the logic and the trace kernel cost a launch, a second
-// round trip of every request through HBM and 30-50 us per round of a frame whose rounds are 60-600 us (round 2: 49 + 29 us
-// of a 0.98 ms frame, a quarter of what one of eight ranks does per frame).  An ORDERED round's entries are keyed by predicted
-// cell visits and counted into RT_WF_SORT_BINS classes on the way (per wave in LDS, one global atomic instruction per wave);
-// wf_scatter_kernel turns ranks into positions, longest class first.  Only the ORDER and GROUPING in which cells are visited
-// changes.  Cutting costs work (every entry has a start-up and a test batch of its own, segments behind a hit are wasted), so
-// the aimed-at cell visits per segment depend on how many rays the round has (RtRoundMode::segLen, chosen by the host from
-// the launch plan): a round that fills the GPU several times over is bound by its total work and is not cut at all (cutting
-// at 384/256/192/128 visits measured 1-13 % slower), a round with few rays is cut finely enough to occupy every SIMD.
+// Who makes the DDA start state of a ray (no kernel of its own: a set-up kernel between logic and trace cost a launch, a second
+// round trip of every ray through HBM and 30-50 us per round of a frame whose rounds are 60-600 us):
+//   * an ORDERED round (many rays: bound by total work, never cut) -- wf_logic_kernel, where the ray is in registers and nearly
+//     every lane spawns one; the entry carries the start state, and its walk-length class (predicted cell visits, exact for a
+//     ray that hits nothing) is counted on the way (per wave in LDS, one global atomic instruction per wave); wf_scatter_kernel
+//     turns ranks into positions, longest class first;
+//   * any other round (few rays: bound by its longest chain, cut finely enough to occupy every SIMD) -- wf_trace_kernel<false>,
+//     whose workgroups take a few rays each, plan them with every lane busy, and deal the segments to their lanes.  In a late
+//     round only every tenth path spawns a ray: planning those in the logic kernel ran its whole tail at a tenth of the lanes
+//     (measured: logic round 1 84 -> 167 us).
+// Only the ORDER and GROUPING in which cells are visited changes.  Cutting costs work (every segment has a start-up and a test
+// batch of its own, segments behind a hit are wasted), so the aimed-at cell visits per segment depend on how many rays the
+// round has (RtRoundMode::segLen, chosen by the host from the launch plan).
 #ifndef RT_WF_MAXSEG
 #define RT_WF_MAXSEG 12
 #endif
@@ -314,26 +317,37 @@ __device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t 
     return pos ? c0 + (uint32_t)m : c0 - (uint32_t)m;
 }
 
-// What a ray's entries are made from: its DDA start state (:351-362, :383-385), where it ends, how many cells it will visit if
-// it hits nothing, and into how many segments it is cut.
-struct EntryPlan { DdaState start; uint32_t endCell, visits, nseg; float te; };
+// GetBoxAddress (:174-193) on the LDS planes: strict '<'; packed cx | cy << 8 | cz << 16
+__device__ __forceinline__ uint32_t cell_of(const float *planes, V3 p)
+{
+    int cx = 0, cy = 0, cz = 0;
+#pragma unroll
+    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
+        if (planes[cx + div] < p.x) cx += div;
+        if (planes[(RT_GRID_DIV + 1) + cy + div] < p.y) cy += div;
+        if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < p.z) cz += div;
+    }
+    return (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
+}
 
-__device__ __forceinline__ EntryPlan plan_entries(const float *planes, V3 o, V3 d, float tmin, float tmax, uint32_t segLen)
+// What a ray's walk is made from: its DDA start state (:351-362, :383-385), where it ends (a ray with a finite range: the cell of
+// its far end, :356-362), how many cells it will visit if it hits nothing, and where it leaves the grid (te).
+struct EntryPlan { DdaState start; uint32_t endCell, visits; float te; };
+
+// `haveStart`: the caller knows the start cell (a hit's shadow ray and its bounce ray start at the same point).  `lut` (optional; LDS
+// copy of RtDevScene::cellLut followed by the three scales 256 / box width): where a ray WITHOUT an end cell leaves the grid -- which
+// only predicts the length of its walk -- is estimated with one table read per axis instead of a plane search.
+__device__ __forceinline__ EntryPlan plan_ray(const float *planes, V3 o, V3 d, float tmin, float tmax, bool haveStart = false, uint32_t startCell = 0u,
+                                              const uint8_t *lut = nullptr, const float *lutScale = nullptr)
 {
     EntryPlan p;
     const V3 lo = mk(planes[0], planes[RT_GRID_DIV + 1], planes[2 * (RT_GRID_DIV + 1)]);
     const V3 hi = mk(planes[RT_GRID_DIV], planes[2 * RT_GRID_DIV + 1], planes[3 * RT_GRID_DIV + 2]);
     // start / end cells (:351-362)
-    int cx = 0, cy = 0, cz = 0, ex = 0, ey = 0, ez = 0;
     V3 from = along(o, tmin, d);
     bind_in_cube(from, d, lo, hi);
-#pragma unroll
-    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-        if (planes[cx + div] < from.x) cx += div;
-        if (planes[(RT_GRID_DIV + 1) + cy + div] < from.y) cy += div;
-        if (planes[2 * (RT_GRID_DIV + 1) + cz + div] < from.z) cz += div;
-    }
-    p.start.cell = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)cz << 16);
+    p.start.cell = startCell;
+    if (!haveStart) p.start.cell = cell_of(planes, from);
     p.te = RT_INF;
     V3 to;
     if (tmax < RT_INF) {
@@ -346,32 +360,43 @@ __device__ __forceinline__ EntryPlan plan_entries(const float *planes, V3 o, V3 
         if (d.z != 0.f) { const float t = (((0.f <= d.z) ? hi.z : lo.z) - o.z) / d.z; if (t < p.te) p.te = t; }
         to = (p.te < RT_INF) ? along(o, p.te, d) : from;
     }
-#pragma unroll
-    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2) {
-        if (planes[ex + div] < to.x) ex += div;
-        if (planes[(RT_GRID_DIV + 1) + ey + div] < to.y) ey += div;
-        if (planes[2 * (RT_GRID_DIV + 1) + ez + div] < to.z) ez += div;
-    }
-    // (where a ray without an end cell leaves the grid is a scheduling matter only)
-    p.endCell = (tmax < RT_INF) ? ((uint32_t)ex | ((uint32_t)ey << 8) | ((uint32_t)ez << 16)) : 0xffffffffu;
+    uint32_t last; // (where a ray without an end cell leaves the grid is a scheduling matter only)
+    if (lut && !(tmax < RT_INF)) {
+        const float fx = (to.x - lo.x) * lutScale[0], fy = (to.y - lo.y) * lutScale[1], fz = (to.z - lo.z) * lutScale[2];
+        const int ix = min(255, max(0, (int)fx)), iy = min(255, max(0, (int)fy)), iz = min(255, max(0, (int)fz)); // (a NaN converts to 0)
+        last = (uint32_t)lut[ix] | ((uint32_t)lut[256 + iy] << 8) | ((uint32_t)lut[512 + iz] << 16);
+    } else last = cell_of(planes, to);
+    p.endCell = (tmax < RT_INF) ? last : 0xffffffffu;
+    const int cx = (int)(p.start.cell & 255u), cy = (int)((p.start.cell >> 8) & 255u), cz = (int)(p.start.cell >> 16);
     // distances from the ray ORIGIN to the next plane of each axis (:383-385)
     p.start.dx = (planes[cx + ((0 <= d.x) ? 1 : 0)] - o.x) / d.x;
     p.start.dy = (planes[(RT_GRID_DIV + 1) + cy + ((0 <= d.y) ? 1 : 0)] - o.y) / d.y;
     p.start.dz = (planes[2 * (RT_GRID_DIV + 1) + cz + ((0 <= d.z) ? 1 : 0)] - o.z) / d.z;
     // every step moves one axis by one cell in a fixed direction: visits = Manhattan distance + 1
-    p.visits = (uint32_t)(abs(ex - cx) + abs(ey - cy) + abs(ez - cz)) + 1u;
-    p.nseg = 1;
-    // Only rays without an end cell are cut, and only where every quotient involved is an ordinary number (a zero
-    // direction component makes heads infinite or NaN and the merge argument is not worth stretching to them).
+    p.visits = (uint32_t)(abs((int)(last & 255u) - cx) + abs((int)((last >> 8) & 255u) - cy) + abs((int)(last >> 16) - cz)) + 1u;
+    return p;
+}
+
+// Into how many segments a planned ray is cut when a segment should make about segLen cell visits.  Only rays without an end
+// cell are cut, and only where every quotient involved is an ordinary number (a zero direction component makes heads infinite
+// or NaN and the merge argument is not worth stretching to them); a ray only slightly over the aim is left whole.
+__device__ __forceinline__ uint32_t segments_of(const EntryPlan &p, V3 d, float tmax, uint32_t segLen)
+{
     const float ta = fminf(p.start.dx, fminf(p.start.dy, p.start.dz));
     const bool plain = !(tmax < RT_INF) && d.x != 0.f && d.y != 0.f && d.z != 0.f && p.te < RT_INF && -RT_INF < ta && ta < p.te &&
                        p.start.dx == p.start.dx && p.start.dy == p.start.dy && p.start.dz == p.start.dz && p.start.dx < RT_INF &&
                        p.start.dy < RT_INF && p.start.dz < RT_INF;
-    if (plain && p.visits > segLen + segLen / 4) { // a ray only slightly over the aim is left whole
-        p.nseg = (p.visits + segLen - 1) / segLen;
-        if (p.nseg > RT_WF_MAXSEG) p.nseg = RT_WF_MAXSEG;
-    }
-    return p;
+    if (!plain || p.visits <= segLen + segLen / 4) return 1u;
+    const uint32_t n = (p.visits + segLen - 1) / segLen;
+    return n > RT_WF_MAXSEG ? (uint32_t)RT_WF_MAXSEG : n;
+}
+
+// Cut k (1 <= k < n) of a ray: tau_k = ta + (te - ta) * k / n is non-decreasing in k, and a cut only exists where ta <= tau_k < te,
+// so the cuts that exist are a prefix of 1 .. n - 1: whether cut k and cut k + 1 exist can be told from k alone.
+__device__ __forceinline__ bool cut_at(float ta, float te, uint32_t k, uint32_t n, float &tau)
+{
+    tau = ta + (te - ta) * ((float)k / (float)n);
+    return ta <= tau && tau < te;
 }
 
 // ---- stage 2: per-path state machine ---------------------------------------------------------------------------------
@@ -392,6 +417,9 @@ __device__ __forceinline__ EntryPlan plan_entries(const float *planes, V3 o, V3 
 #endif
 #ifndef RT_WF_LOGIC_WAVES_FIRST
 #define RT_WF_LOGIC_WAVES_FIRST 3
+#endif
+#ifndef RT_WF_LOGIC_WAVES_FIRST_ORDERED
+#define RT_WF_LOGIC_WAVES_FIRST_ORDERED 3
 #endif
 #define RT_WF_LIGHTS_LDS 64
 #ifdef RT_DIAG_LOGIC // diagnostic build: where a wave is at which time, round RT_DIAG_LOGIC (no waits added; scripts/diag_logic.py)
@@ -414,9 +442,11 @@ __device__ __forceinline__ void load_tri_row(const RtDevScene &S, uint32_t tri, 
 }
 
 // FIRST = round 0: every entry is a primary hit (stage, ring positions and the colour so far are known), a path's id is its queue index.
+// ORDERED = the round this launch spawns is an ordered one (next.ordered): its entries are planned and classed here; the other
+// instantiation carries none of that code (its registers are the state machine's).
 // slicesIn = queue slices per kind of THIS round (what logic(round - 1) was told), next = how the round this launch spawns is laid out.
-template <bool FIRST>
-__global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
+template <bool FIRST, bool ORDERED>
+__global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORDERED : RT_WF_LOGIC_WAVES_FIRST) : RT_WF_LOGIC_WAVES) void wf_logic_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round,
                                                                                                              const uint32_t slicesIn, const RtRoundMode next)
 {
     __shared__ Shared sh; // the texel/255 table and the split planes (for the entries of the rays spawned here)
@@ -424,14 +454,17 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
     __shared__ float4 ltPosRadius[RT_WF_LIGHTS_LDS], ltDirSpread[RT_WF_LIGHTS_LDS], ltColHalf[RT_WF_LIGHTS_LDS];
     __shared__ int ltType[RT_WF_LIGHTS_LDS];
     // an ordered round's classes, per wave: entries of this wave per walk-length class, then where the class's ranks of this wave start
-    __shared__ uint32_t waveHist[4][RT_WF_SORT_BINS], waveBase[4][RT_WF_SORT_BINS];
-    __shared__ uint8_t itemOwner[4][64 * (RT_WF_MAXSEG - 1)]; // per wave: which lane's ray the i-th further segment belongs to
+    __shared__ uint32_t waveHist[ORDERED ? 4 : 1][RT_WF_SORT_BINS], waveBase[ORDERED ? 4 : 1][RT_WF_SORT_BINS];
+    __shared__ uint8_t cellLut[ORDERED ? 3 * 256 : 4];
+    __shared__ float lutScale[3];
     static_assert(RT_WF_SORT_BINS == 64, "one class per lane");
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
-    {
+    if (ORDERED) {
         float *pl = &sh.planes[0][0];
         for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) pl[i] = S.boxMin[i];
         waveHist[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
+        if (threadIdx.x < 3 * 256 / 4) reinterpret_cast<uint32_t *>(cellLut)[threadIdx.x] = reinterpret_cast<const uint32_t *>(S.cellLut)[threadIdx.x];
+        if (threadIdx.x < 3) lutScale[threadIdx.x] = 256.f / (S.boxMin[threadIdx.x * (RT_GRID_DIV + 1) + RT_GRID_DIV] - S.boxMin[threadIdx.x * (RT_GRID_DIV + 1)]);
     }
     if (threadIdx.x < RT_WF_LIGHTS_LDS && threadIdx.x < S.lightCount) {
         const uint32_t k = threadIdx.x;
@@ -832,19 +865,12 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
         slotLa += W.capacity + outShard * sliceCapOut;
         asm volatile("" : "+v"(a), "+v"(slot), "+v"(slotLa)); // (addresses made here, not carried across the state machine)
         if (slot != 0xfffffff0u) DG(8);
-        // The rays of the next round become TRACE ENTRIES now: DDA start state, segments, and -- for a round that will be ordered --
-        // the walk-length class of every entry (stage "trace entries" above).  Main rays first, then the look-ahead rays: one plan
-        // in registers at a time.
-        uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0; // ordered round: segment 0's class and its rank inside this wave
-        uint32_t itemsM = 0, itemsL = 0, itemsAtM = 0, itemsAtL = 0; // further segments of this wave's main / look-ahead rays: how many, and where in region B
+        // The rays of the next round go to their queue slots now.  An ORDERED round (many rays, nearly every lane has one): as complete
+        // trace entries -- DDA start state and walk-length class -- so that nothing stands between this kernel and the walk but the
+        // placing of the classes.  Any other round: the ray alone; wf_trace_kernel<false> plans and cuts it (stage "trace entries").
+        uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0; // ordered round: the entry's class and its rank inside this wave
+        uint32_t cellM = 0;
         const uint32_t copy = waveId % RT_WF_SORT_COPIES;
-        // walk-length class of an entry that will make v cell visits if it hits nothing (scheduling only).  Two scales: segments of a
-        // finely cut round differ by a few visits, uncut rays by hundreds; class 0 = longest
-        auto visit_class = [](uint32_t v) -> uint32_t {
-            if ((int)v < 1) v = 1;
-            if (v > 767u) v = 767u;
-            return (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
-        };
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
             const bool has = which ? emitLa : emit;
@@ -852,138 +878,36 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
             const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
             const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
             const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
-            EntryPlan plan;
-            plan.nseg = 0; plan.visits = 1; plan.endCell = 0xffffffffu; plan.te = RT_INF;
-            plan.start.cell = 0; plan.start.dx = 0.f; plan.start.dy = 0.f; plan.start.dz = 0.f;
-#ifdef RT_X_FAKEPLAN
-            if (has) { plan.nseg = 1; plan.start.cell = (__float_as_uint(o.x) & 0xffffffu); plan.start.dx = o.x; plan.start.dy = o.y; plan.start.dz = o.z; plan.visits = 100; }
-#else
-            if (has) plan = plan_entries(planes, o, d, tmin, tmax, next.segLen);
-#endif
-            uint32_t nseg = plan.nseg, extraAt = 0, items = 0, before = 0;
-            // Room in region B for the further segments of this wave's rays: one atomic per wave that cuts anything.  A reservation is
-            // never undone (an add followed by a subtract is not atomic across waves: a later, smaller reservation could land inside
-            // the range the subtract gives back).  A count past extraCap just means "region B is full"; every reader clamps it.  The
-            // one wave whose range straddles the end owns [at, extraCap) and marks those slots empty; waves after it start past the
-            // end and own nothing.  No room, no cutting: the wave's rays stay whole.
-            if (__ballot(nseg > 1u) != 0ull) { // wave-uniform
-                const uint32_t extraMine = nseg > 1u ? nseg - 1u : 0u;
-                uint32_t incl = extraMine;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t up = __shfl_up(incl, off, 64);
-                    if ((int)lane >= off) incl += up;
-                }
-                items = (uint32_t)__shfl((int)incl, 63, 64);
-                before = incl - extraMine;
-                uint32_t base = 0;
-                if (lane == 0u) base = atomicAdd(&ctlOut[RT_WF_CTL_EXTRA], items);
-                base = (uint32_t)__shfl((int)base, 0, 64);
-                if ((uint64_t)base + items > (uint64_t)W.extraCap) {
-                    for (uint32_t i = base + lane; i < W.extraCap; i += 64) {
-                        W.ent[outq][4 * (size_t)(2u * W.capacity + i)].x = 0xffffffffu;
-                        W.sortRank[2u * W.capacity + i] = 0xffffffffu;
-                    }
-                    if (nseg > 1u) nseg = 1u;
-                    items = 0;
-                }
-                extraAt = 2u * W.capacity + base; // region B of the entry array starts after the 2*capacity queue slots
-                // who owns item i (= further segment before + j - 1 of lane `owner`)
-                for (uint32_t j = 1; j < nseg; ++j) itemOwner[wave][before + j - 1] = (uint8_t)lane;
-            }
-            if (which) { itemsL = items; itemsAtL = extraAt; } else { itemsM = items; itemsAtM = extraAt; }
-            // Segment k of a ray goes from the walk's state at tau_k to the start cell of segment k + 1 (tau_0 = the ray's own start):
-            // tau_k = ta + (te - ta) * k / nseg is non-decreasing in k and a cut only exists where ta <= tau_k < te, so the cuts that
-            // exist are a prefix of 1 .. nseg - 1 -- every lane can tell from k alone whether cut k and cut k + 1 exist.
-            const float ta = fminf(plan.start.dx, fminf(plan.start.dy, plan.start.dz));
-            const uint32_t perSeg = nseg ? (plan.visits + nseg - 1) / nseg : 1u;
-            auto cut_at = [](float ta_, float te_, uint32_t k, uint32_t n, float &tau) -> bool {
-                tau = ta_ + (te_ - ta_) * ((float)k / (float)n);
-                return ta_ <= tau && tau < te_;
-            };
-            if (has) { // segment 0, at the ray's queue index; where it ends is filled in by the lane that makes cut 1
-                W.pathOf[outq][mine] = a;
-                W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
-                if (which) W.laSlot[a] = mine;
-                float tau1;
-                const bool cut1 = nseg > 1u && cut_at(ta, plan.te, 1u, nseg, tau1);
-                uint32_t tag = 0u, rank = 0u;
-                if (next.ordered) {
-                    const uint32_t bin = visit_class(cut1 ? perSeg : plan.visits);
-                    rank = atomicAdd(&waveHist[wave][bin], 1u);
-                    tag = bin;
-                    if (which) { binL = bin; rankL = rank; } else { binM = bin; rankM = rank; }
-                }
-                uint4 *e = W.ent[outq] + 4 * (size_t)mine;
-                if (nseg > 1u) { // (.z comes from another lane: not written here, so that the two stores cannot meet)
-                    *reinterpret_cast<uint2 *>(e) = make_uint2(mine, plan.start.cell | (tag << 24));
-                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
-                } else e[0] = make_uint4(mine, plan.start.cell | (tag << 24), plan.endCell, excluded);
-#ifndef RT_X_NOENTSTORE
+            if (!has) continue;
+            W.pathOf[outq][mine] = a;
+            W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
+            if (which) W.laSlot[a] = mine;
+            uint4 *e = W.ent[outq] + 4 * (size_t)mine;
+            if (ORDERED) {
+                // (a hit's look-ahead ray starts where its shadow ray starts: one plane search for the two -- when the start is the origin
+                // itself, tmin = 0, and lies inside the grid's box, so that BindInCube (:265-322) moves it for neither direction)
+                const bool sameStart = which && emit && lo3.x == ro.x && lo3.y == ro.y && lo3.z == ro.z && latmin == 0.f && rtmin == 0.f &&
+                                       planes[0] <= o.x && o.x <= planes[RT_GRID_DIV] && planes[RT_GRID_DIV + 1] <= o.y && o.y <= planes[2 * RT_GRID_DIV + 1] &&
+                                       planes[2 * (RT_GRID_DIV + 1)] <= o.z && o.z <= planes[3 * RT_GRID_DIV + 2];
+                const EntryPlan plan = plan_ray(planes, o, d, tmin, tmax, sameStart, cellM, cellLut, lutScale);
+                if (!which) cellM = plan.start.cell;
+                // walk-length class (scheduling only).  Two scales: short walks differ by a few visits, long ones by hundreds; class 0 = longest
+                uint32_t v = plan.visits;
+                if (v > 767u) v = 767u;
+                const uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+                const uint32_t rank = atomicAdd(&waveHist[wave][bin], 1u);
+                if (which) { binL = bin; rankL = rank; } else { binM = bin; rankM = rank; }
+                e[0] = make_uint4(mine, plan.start.cell, plan.endCell, excluded);
                 e[1] = make_uint4(__float_as_uint(plan.start.dx), __float_as_uint(plan.start.dy), __float_as_uint(plan.start.dz), __float_as_uint(tmin));
-                e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-                e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank); // (rank inside this wave's class for now; segment 0)
-#endif
+            } else {
+                reinterpret_cast<uint32_t *>(e)[3] = excluded;
+                reinterpret_cast<uint32_t *>(e)[7] = __float_as_uint(tmin);
             }
-            if (items == 0u) continue; // wave-uniform
-            // The further segments, one per lane whoever's ray it is: a lane that shades one of the few hits of a late round would
-            // otherwise make its ray's up to 11 cuts one after the other while the wave's other lanes wait (measured: 40 % of a chunk's time).
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i0 = 0; i0 < items; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                const bool live = i < items;
-                const uint32_t owner = live ? itemOwner[wave][i] : 0u;
-                const uint32_t k = i - (uint32_t)__shfl((int)before, owner, 64) + 1u; // this lane makes cut k of `owner`'s ray
-                const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
-                const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
-                const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64), pta = __shfl(ta, owner, 64), pte = __shfl(plan.te, owner, 64);
-                const uint32_t pexcl = __shfl(excluded, owner, 64), pmine = __shfl(mine, owner, 64), pcell = __shfl(plan.start.cell, owner, 64);
-                const uint32_t pnseg = __shfl(nseg, owner, 64), pvisits = __shfl(plan.visits, owner, 64), pend = __shfl(plan.endCell, owner, 64);
-                if (!live) continue;
-                const uint32_t at = extraAt + i; // entry of segment k
-                float tau, tauNext;
-                const bool cut = cut_at(pta, pte, k, pnseg, tau);
-                const bool cutNext = k + 1u < pnseg && cut_at(pta, pte, k + 1u, pnseg, tauNext);
-                uint32_t *prev = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)(k == 1u ? pmine : at - 1u));
-                uint32_t *self = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)at);
-                if (!cut) { // rounding left no room for this cut: the segment before runs to the ray's end, this one does not exist
-                    prev[2] = pend;
-                    self[0] = 0xffffffffu;
-                    W.sortRank[at] = 0xffffffffu;
-                    continue;
-                }
-                DdaState st;
-                // (counting the crossings with T <= tau from the ray's start cell: the state does not depend on where counting begins)
-                const uint32_t nx = axis_state_at(planes, pcell & 255u, po.x, pd.x, tau, st.dx);
-                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (pcell >> 8) & 255u, po.y, pd.y, tau, st.dy);
-                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), pcell >> 16, po.z, pd.z, tau, st.dz);
-                st.cell = nx | (ny << 8) | (nz << 16);
-                prev[2] = st.cell; // the segment before ends where this one starts
-                uint32_t tag = 0u, rank = 0u;
-                if (next.ordered) {
-                    const uint32_t per = (pvisits + pnseg - 1) / pnseg;
-                    const uint32_t bin = visit_class(cutNext ? per : pvisits - per * k);
-                    rank = atomicAdd(&waveHist[wave][bin], 1u);
-                    tag = bin;
-                }
-                *reinterpret_cast<uint2 *>(self) = make_uint2(pmine, st.cell | (tag << 24));
-                self[3] = pexcl;
-                if (!cutNext) self[2] = pend; // the ray's last segment
-                uint4 *e = reinterpret_cast<uint4 *>(self);
-                e[1] = make_uint4(__float_as_uint(st.dx), __float_as_uint(st.dy), __float_as_uint(st.dz), __float_as_uint(ptmin));
-                e[2] = make_uint4(__float_as_uint(po.x), __float_as_uint(po.y), __float_as_uint(po.z), __float_as_uint(ptmax));
-                e[3] = make_uint4(__float_as_uint(pd.x), __float_as_uint(pd.y), __float_as_uint(pd.z), rank | (k << 24));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier(); // (itemOwner is rewritten for the look-ahead rays)
+            e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+            e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
         }
         if (copy != 0xfffffff0u) DG(9);
-#ifdef RT_X_NOHIST
-        if (false) {
-#else
-        if (next.ordered) {
-#endif
+        if (ORDERED) {
             // rank inside the (class, copy) = this wave's base + rank inside the wave: lane b fetches the base of class b (one atomic
             // instruction for the wave's up to 64 classes).  One wave, in-order LDS: wavefront-scope fences are all the ordering needed.
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -999,17 +923,6 @@ __global__ __launch_bounds__(256, FIRST ? RT_WF_LOGIC_WAVES_FIRST : RT_WF_LOGIC_
             __builtin_amdgcn_wave_barrier();
             if (emit) { W.sortRank[slot] = waveBase[wave][binM] + rankM; W.sortTag[slot] = (uint16_t)(binM | (copy << 6)); }
             if (emitLa) { W.sortRank[slotLa] = waveBase[wave][binL] + rankL; W.sortTag[slotLa] = (uint16_t)(binL | (copy << 6)); }
-#pragma unroll 1
-            for (int which = 0; which < 2; ++which) { // the further segments: class and rank in the wave are in the entries
-                const uint32_t items = which ? itemsL : itemsM, at0 = which ? itemsAtL : itemsAtM;
-                for (uint32_t i = lane; i < items; i += 64) {
-                    const uint4 *e = W.ent[outq] + 4 * (size_t)(at0 + i);
-                    if (e[0].x == 0xffffffffu) continue;
-                    const uint32_t bin = e[0].y >> 24;
-                    W.sortRank[at0 + i] = waveBase[wave][bin] + (e[3].w & 0xffffffu);
-                    W.sortTag[at0 + i] = (uint16_t)(bin | (copy << 6));
-                }
-            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier(); // (waveBase is overwritten by this wave's next chunk)
         }
@@ -1046,8 +959,7 @@ __device__ __forceinline__ uint32_t slice_count(const uint32_t *ctl, uint32_t sl
     return ctl[RT_WF_CTL_COUNTS + kind * RT_WF_SHARDS + shard];
 }
 
-// Work items: the used 256-entry blocks of the queue slices (region A: segment 0 of every ray, in queue order), then the
-// blocks of region B (further segments, densely packed); a fixed grid takes them in turn.  The logic kernel left a rank inside
+// Work items: the used 256-entry blocks of the queue slices; a fixed grid takes them in turn.  The logic kernel left a rank inside
 // its (class, copy) and the class itself per entry; the classes' sizes are in the round's histogram.
 __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round, const uint32_t slices)
 {
@@ -1078,28 +990,16 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
     __syncthreads();
     const uint32_t usedBlocks = (max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3])) + 255u) >> 8;
     const uint32_t itemsA = 2u * slices * usedBlocks;
-    const uint32_t extra = min(ctl[RT_WF_CTL_EXTRA], W.extraCap); // the count runs past the capacity when region B filled up (wf_logic_kernel)
-    const uint32_t itemsB = (extra + 255u) >> 8;
-    for (uint32_t item = blockIdx.x; item < itemsA + itemsB; item += gridDim.x) {
-        uint32_t mine = 0;
-        bool valid = false;
-        if (item < itemsA) {
-            const uint32_t sl = item % (2u * slices);
-            const uint32_t local = (item / (2u * slices)) * 256 + threadIdx.x;
-            valid = local < slice_count(ctl, slices, sl);
-            mine = slice_first(W, slices, sl) + local;
-        } else {
-            const uint32_t local = (item - itemsA) * 256 + threadIdx.x;
-            valid = local < extra;
-            mine = 2u * W.capacity + local;
-        }
+    for (uint32_t item = blockIdx.x; item < itemsA; item += gridDim.x) {
+        const uint32_t sl = item % (2u * slices);
+        const uint32_t local = (item / (2u * slices)) * 256 + threadIdx.x;
+        const bool valid = local < slice_count(ctl, slices, sl);
+        const uint32_t mine = slice_first(W, slices, sl) + local;
         if (valid) {
             // only the ORDER is written: the trace kernel gathers its 64-byte entries through it
             const uint32_t rank = W.sortRank[mine];
-            if (rank != 0xffffffffu) { // not an unused reservation
-                const uint32_t tag = W.sortTag[mine]; // bin | copy << 6
-                W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + rank] = mine;
-            }
+            const uint32_t tag = W.sortTag[mine]; // bin | copy << 6
+            W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + rank] = mine;
         }
     }
 }
@@ -1133,6 +1033,8 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 #ifndef RT_WF_LEAN_STALL
 #define RT_WF_LEAN_STALL 64           // test once (lanes without room for another phase) x this exceeds the lanes still walking
 #endif
+#define RT_WF_GROUP_RAYS 128          // rays a workgroup of wf_trace_kernel<false> plans at most (RtRoundMode::groupRays): its first two waves
+template <bool ORDERED>
 __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const RtDevScene S, const RtWavefront W, const uint32_t round, const RtRoundMode mode)
 {
     __shared__ float planes[3 * (RT_GRID_DIV + 1)];
@@ -1142,22 +1044,31 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     __shared__ uint32_t moreOf[4][2][RT_WF_MORE_ITEMS];                 // per wave: further candidates under test {owner | cell order << 6}, {pair}
     __shared__ uint32_t moreCount[4];
     static_assert(RT_WF_LEAN_LIST <= 16, "hit_key: 4 bits of cell order");
+    // <false> only: the workgroup's rays as planned by its first lanes {o,tmin} {d,tmax} {excluded, q, start cell, end cell} {dx,dy,dz,te},
+    // the first segment of every ray in the workgroup's list of segments, and whose ray a segment is.  They live in the cell
+    // lists' memory: the planning is over before the walk begins, and 5 KB more of LDS would cost the kernel its fifth workgroup per CU.
+    static_assert(sizeof(float4) * 4 * RT_WF_GROUP_RAYS + 4 * (RT_WF_GROUP_RAYS + 1) + 256 <= sizeof(cellList) && RT_WF_GROUP_RAYS == 128, "the plan tables fit the cell lists; waves 0 and 1 plan");
+    float4 *rayO = reinterpret_cast<float4 *>(&cellList[0][0]), *rayD = rayO + RT_WF_GROUP_RAYS, *rayT = rayD + RT_WF_GROUP_RAYS;
+    uint4 *rayX = reinterpret_cast<uint4 *>(rayT + RT_WF_GROUP_RAYS);
+    uint32_t *segFirst = reinterpret_cast<uint32_t *>(rayX + RT_WF_GROUP_RAYS);
+    uint8_t *segOwner = reinterpret_cast<uint8_t *>(segFirst + RT_WF_GROUP_RAYS + 1); // [256]: a workgroup's segments are one per lane at most
 
-    // Which 256 entries this workgroup takes.
-    //   ordered round:  block i of the sorted order, through sortedIdx -- the hardware dispatches workgroups in order, so the longest
-    //                   walks start first and a free slot always gets the longest work left;
-    //   other rounds:   the blocks of region B (further segments) first, then the 256-entry blocks of the queue slices, slice-minor
-    //                   (block b of every slice before block b + 1 of any: slices fill evenly).
+    // Which rays this workgroup takes.
+    //   ordered round:  256 entries, block i of the sorted order, through sortedIdx -- the hardware dispatches workgroups in order, so
+    //                   the longest walks start first and a free slot always gets the longest work left;
+    //   other rounds:   mode.groupRays rays of one queue slice, slice-minor (piece b of every slice before piece b + 1 of any: slices
+    //                   fill evenly); the workgroup plans them, cuts them, and deals the segments to its lanes 256 at a time.
     // A planned frame's grid is sized from the same frame's previous rendering (rt_api.cpp); should it be too small the host is told
     // and renders the frame again with the worst-case grid (a loop that strides over the rest measured 4 % slower).
     const uint32_t *ctl = W.ctl + (round % 3) * RT_WF_CTL_WORDS;
     const uint32_t par = round & 1;
-    const uint32_t extra = min(ctl[RT_WF_CTL_EXTRA], W.extraCap);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && round < RT_WF_ROUND_LOG) reinterpret_cast<uint32_t *>(W.roundLog + round)[2] = extra;
-    uint32_t mine = 0;
+#ifdef RT_DIAG_STAMPS
+    const unsigned long long dgK0 = diag_stamp();
+#endif
+    uint32_t mine = 0, segments = 0;
     bool active = false;
-    if (mode.ordered) {
+    if (ORDERED) {
         const uint32_t total = ctl[RT_WF_CTL_TOTAL];
         const uint32_t blocksUsed = (total + 255u) >> 8;
         if (blockIdx.x == 0 && threadIdx.x == 0 && blocksUsed > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
@@ -1165,42 +1076,150 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         const uint32_t at = blockIdx.x * 256 + threadIdx.x;
         active = at < total;
         if (active) mine = W.sortedIdx[at];
+        for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
+        __syncthreads();
     } else {
-        const uint32_t blocksB = (extra + 255u) >> 8, perRow = 2u * mode.slices;
-        const uint32_t rows = gridDim.x > blocksB ? (gridDim.x - blocksB) / perRow : 0u;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && rows == 0u) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
-        if (blockIdx.x < blocksB) {
-            const uint32_t local = blockIdx.x * 256 + threadIdx.x;
-            active = local < extra;
-            mine = 2u * W.capacity + local;
-        } else {
-            const uint32_t item = blockIdx.x - blocksB;
-            const uint32_t sl = item % perRow, row = item / perRow;
-            if (row >= rows) return; // (an incomplete last row of the grid)
-            const uint32_t count = slice_count(ctl, mode.slices, sl);
-            if (threadIdx.x == 0 && row + 1 == rows && count > rows * 256u) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
-            if (row * 256u >= count) return; // this slice is shorter
-            const uint32_t local = row * 256 + threadIdx.x;
-            active = local < count;
-            mine = slice_first(W, mode.slices, sl) + local;
+        // Workgroup i takes piece `row` of queue slice `sl`, pieces numbered through the slices in turn -- found by adding up the
+        // slices' piece counts, not by arithmetic on i: a grid striped "slice = i % slices" puts the workgroups of the empty slices (a
+        // late round has no look-ahead rays) at a fixed stride, the hardware deals workgroups to XCDs and CUs round-robin, and half
+        // of the CUs ended up with all of the round's work (measured: 64 -> 130 us).
+        const uint32_t group = min(mode.groupRays, (uint32_t)RT_WF_GROUP_RAYS);
+        __shared__ uint32_t pieceWave[4], pieceAt[2];
+        uint32_t sl = 0, row = 0, count = 0;
+        {
+            static_assert(2 * RT_WF_SHARDS == 512, "two queue slices per thread");
+            const uint32_t s0 = threadIdx.x, s1 = 256u + threadIdx.x;
+            const uint32_t c0 = s0 < 2u * mode.slices ? slice_count(ctl, mode.slices, s0) : 0u, c1 = s1 < 2u * mode.slices ? slice_count(ctl, mode.slices, s1) : 0u;
+            const uint32_t p0 = (c0 + group - 1u) / group, p1 = (c1 + group - 1u) / group;
+            // pieces before slice s0 (slices 0..255 first, then 256..511): scan of p0 over the workgroup, then of p1 behind it
+            uint32_t i0 = p0, i1 = p1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u0 = __shfl_up(i0, off, 64), u1 = __shfl_up(i1, off, 64);
+                if ((int)lane >= off) { i0 += u0; i1 += u1; }
+            }
+            if (lane == 63) { pieceWave[wave] = i0; }
+            __syncthreads();
+            uint32_t before0 = 0, all0 = 0;
+            for (uint32_t w = 0; w < 4; ++w) { if (w < wave) before0 += pieceWave[w]; all0 += pieceWave[w]; }
+            __syncthreads();
+            if (lane == 63) { pieceWave[wave] = i1; }
+            __syncthreads();
+            uint32_t before1 = all0, all1 = all0;
+            for (uint32_t w = 0; w < 4; ++w) { if (w < wave) before1 += pieceWave[w]; all1 += pieceWave[w]; }
+            const uint32_t first0 = before0 + i0 - p0, first1 = before1 + i1 - p1;
+            if (blockIdx.x == 0 && threadIdx.x == 0 && all1 > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+            if (blockIdx.x >= all1) return; // whole workgroup beyond the round's pieces
+            if (first0 <= blockIdx.x && blockIdx.x < first0 + p0) { pieceAt[0] = s0; pieceAt[1] = blockIdx.x - first0; }
+            if (first1 <= blockIdx.x && blockIdx.x < first1 + p1) { pieceAt[0] = s1; pieceAt[1] = blockIdx.x - first1; }
+            __syncthreads();
+            sl = pieceAt[0]; row = pieceAt[1];
+            count = slice_count(ctl, mode.slices, sl);
         }
+        for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
+        __syncthreads();
+        // The first lanes plan the workgroup's rays: every lane busy, where the logic kernel would have planned one ray in ten lanes.
+        // A workgroup takes every rowsUsed-th ray of its slice, not a stretch of it: neighbours in the queue are neighbours in the
+        // image, their rays are alike, and a stretch of long rays made one workgroup's list of segments two or three times the
+        // others' (the round lasts as long as its slowest workgroup: 64 -> 160 us).
+        const uint32_t rowsUsed = (count + group - 1u) / group;
+        __shared__ uint32_t planWave[2];
+        uint32_t n = 0;
+        const uint32_t local = row + threadIdx.x * rowsUsed;
+        const bool planner = threadIdx.x < group && local < count; // (group <= 128: waves 0 and 1)
+        if (planner) {
+            const uint32_t q = slice_first(W, mode.slices, sl) + local;
+            const uint4 *e = W.ent[par] + 4 * (size_t)q;
+            const uint32_t excl = reinterpret_cast<const uint32_t *>(e)[3];
+            const float tmin = __uint_as_float(reinterpret_cast<const uint32_t *>(e)[7]);
+            const uint4 c2 = e[2], c3 = e[3];
+            const V3 o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)), d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+            const float tmax = __uint_as_float(c2.w);
+            const EntryPlan plan = plan_ray(planes, o, d, tmin, tmax);
+            n = segments_of(plan, d, tmax, mode.segLen);
+            rayO[threadIdx.x] = pack4(o, tmin); rayD[threadIdx.x] = pack4(d, tmax);
+            rayX[threadIdx.x] = make_uint4(excl, q, plan.start.cell, plan.endCell);
+            rayT[threadIdx.x] = make_float4(plan.start.dx, plan.start.dy, plan.start.dz, plan.te);
+        }
+        // one pass of 256 lanes must do: a workgroup whose rays would make more segments cuts them coarser (at most 128 + one per ray)
+        if (wave < 2) {
+            uint32_t sum = n;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            if (lane == 0) planWave[wave] = sum;
+        }
+        __syncthreads();
+        const uint32_t all = planWave[0] + planWave[1];
+        __syncthreads();
+        if (wave < 2) {
+            if (all > 256u && n > 1u) n = max(1u, n * 128u / all);
+            uint32_t incl = n;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if ((int)lane >= off) incl += up;
+            }
+            if (lane == 63) planWave[wave] = incl;
+            n = incl - n; // (this lane's first segment, inside its wave)
+        }
+        __syncthreads();
+        if (wave < 2) {
+            const uint32_t nextFirst = (uint32_t)__shfl_down((int)n, 1, 64); // (by every lane: a shuffle reads nothing from a lane that sits it out)
+            const uint32_t first = n + (wave == 1 ? planWave[0] : 0u), mineN = (lane == 63 ? planWave[wave] : nextFirst) - n;
+            segFirst[threadIdx.x] = first;
+            if (threadIdx.x == 127) segFirst[128] = planWave[0] + planWave[1];
+            for (uint32_t k = 0; k < mineN; ++k) segOwner[first + k] = (uint8_t)threadIdx.x;
+        }
+        __syncthreads();
+        segments = segFirst[128];
     }
-    for (int i = threadIdx.x; i < 3 * (RT_GRID_DIV + 1); i += 256) planes[i] = S.boxMin[i];
-    __syncthreads();
 
-    for (uint32_t once = 0; once < 1u; ++once) {
+    // an ordered round: the workgroup's 256 entries; any other round: the workgroup's segments (256 at most, see above)
+    for (uint32_t pass = 0; pass < 1u; ++pass) {
     uint32_t q = 0, excluded = RT_NONE, cell = 0, endCell = 0xffffffffu, seg = 0;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
     float tmin = 0.f, tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    if (active) {
-        const uint4 *e = W.ent[par] + 4 * (size_t)mine;
-        const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
-        q = c0.x; cell = c0.y & 0xffffffu; endCell = c0.z; excluded = c0.w;
-        if (q == 0xffffffffu) active = false; // an unused reservation in region B
-        dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
-        o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
-        d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
-        seg = c3.w >> 24;
+    if (ORDERED) {
+        if (active) {
+            const uint4 *e = W.ent[par] + 4 * (size_t)mine;
+            const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
+            q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
+            dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
+            o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
+            d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+        }
+    } else {
+        const uint32_t i = threadIdx.x;
+        active = i < segments;
+        if (active) {
+            const uint32_t owner = segOwner[i];
+            const uint32_t k = i - segFirst[owner], n = segFirst[owner + 1] - segFirst[owner];
+            const float4 ro = rayO[owner], rd = rayD[owner], rt = rayT[owner];
+            const uint4 rx = rayX[owner];
+            o = xyz(ro); tmin = ro.w; d = xyz(rd); tmax = rd.w; excluded = rx.x; q = rx.y; seg = k;
+            // segment k goes from the walk's state at tau_k (tau_0: the ray's own start) to the start cell of segment k + 1
+            const float ta = fminf(rt.x, fminf(rt.y, rt.z)), te = rt.w;
+            float tau;
+            cell = rx.z; dx = rt.x; dy = rt.y; dz = rt.z;
+            if (k > 0u) {
+                if (cut_at(ta, te, k, n, tau)) {
+                    // (counting the crossings with T <= tau from the ray's start cell: the state does not depend on where counting begins)
+                    const uint32_t nx = axis_state_at(planes, rx.z & 255u, o.x, d.x, tau, dx);
+                    const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (rx.z >> 8) & 255u, o.y, d.y, tau, dy);
+                    const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), rx.z >> 16, o.z, d.z, tau, dz);
+                    cell = nx | (ny << 8) | (nz << 16);
+                } else active = false; // rounding left no room for this cut: the segment before runs to the ray's end
+            }
+            endCell = rx.w;
+            if (active && k + 1u < n && cut_at(ta, te, k + 1u, n, tau)) {
+                float unused;
+                const uint32_t nx = axis_state_at(planes, rx.z & 255u, o.x, d.x, tau, unused);
+                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (rx.z >> 8) & 255u, o.y, d.y, tau, unused);
+                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), rx.z >> 16, o.z, d.z, tau, unused);
+                endCell = nx | (ny << 8) | (nz << 16);
+            }
+        }
+        __syncthreads(); // the plan tables become the cell lists
     }
     const bool fastWave = S.planesTame && W.fastQuotient && __ballot(active && !(tame_origin(o.x) && tame_origin(o.y) && tame_origin(o.z) &&
                                                                                tame_direction(d.x) && tame_direction(d.y) && tame_direction(d.z))) == 0ull;
@@ -1459,13 +1478,13 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         break;
     }
 #ifdef RT_DIAG_STAMPS
-    if (lane == 0) { // cycle anatomy of this wave (scripts/diag_stamps.py)
+    if (lane == 0 && round == RT_DIAG_STAMPS) { // cycle anatomy of this wave in round RT_DIAG_STAMPS (scripts/diag_stamps.py); [5] = before the walk
         atomicAdd(&S.stats[0], diag_stamp() - dgStart); atomicAdd(&S.stats[1], dgWalk); atomicAdd(&S.stats[2], dgTest);
-        atomicAdd(&S.stats[3], dgWalkIters); atomicAdd(&S.stats[4], dgBatches); atomicAdd(&S.stats[5], dgSteps);
+        atomicAdd(&S.stats[3], dgWalkIters); atomicAdd(&S.stats[4], dgBatches); atomicAdd(&S.stats[5], dgStart - dgK0);
         atomicAdd(&S.stats[6], 1ull); atomicAdd(&S.stats[7], dgItems);
     }
 #endif
-    } // the wave's 64 entries
+    } // passes
 }
 
 // ---- stage 4: samples -> u16 planes -----------------------------------------------------------------------------------
@@ -1522,15 +1541,20 @@ extern "C" hipError_t rtw_launch_primary(const RtDevScene *scene, const RtWavefr
     return hipGetLastError();
 }
 
-static bool mode_ok(const RtRoundMode &m) { return m.slices >= 1u && m.slices <= RT_WF_SHARDS && (m.slices & (m.slices - 1u)) == 0u && m.segLen >= 1u; }
+static bool mode_ok(const RtRoundMode &m)
+{
+    return m.slices >= 1u && m.slices <= RT_WF_SHARDS && (m.slices & (m.slices - 1u)) == 0u && m.segLen >= 1u && m.groupRays >= 1u && m.groupRays <= RT_WF_GROUP_RAYS;
+}
 
 // slicesIn: the queue slices of the round this launch consumes; next: the layout of the round it spawns (next.slices <= slicesIn)
 extern "C" hipError_t rtw_launch_logic(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, uint32_t slicesIn, const RtRoundMode *next, hipStream_t stream)
 {
     if (blocks % (RT_WF_SHARDS / 4) != 0) return hipErrorInvalidValue; // a whole number of waves per queue slice (wf_logic_kernel)
     if (!mode_ok(*next) || slicesIn < next->slices || slicesIn > RT_WF_SHARDS || (slicesIn & (slicesIn - 1u)) != 0u) return hipErrorInvalidValue;
-    if (round == 0u) hipLaunchKernelGGL(wf_logic_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
-    else hipLaunchKernelGGL(wf_logic_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
+    if (round == 0u && next->ordered) hipLaunchKernelGGL((wf_logic_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
+    else if (round == 0u) hipLaunchKernelGGL((wf_logic_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
+    else if (next->ordered) hipLaunchKernelGGL((wf_logic_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
+    else hipLaunchKernelGGL((wf_logic_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, slicesIn, *next);
     return hipGetLastError();
 }
 
@@ -1546,7 +1570,8 @@ extern "C" hipError_t rtw_launch_scatter(const RtWavefront *wf, uint32_t round, 
 extern "C" hipError_t rtw_launch_trace(const RtDevScene *scene, const RtWavefront *wf, uint32_t round, uint32_t blocks, const RtRoundMode *mode, hipStream_t stream)
 {
     if (!mode_ok(*mode)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wf_trace_kernel, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, *mode);
+    if (mode->ordered) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, *mode);
+    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(blocks), dim3(256), 0, stream, *scene, *wf, round, *mode);
     return hipGetLastError();
 }
 

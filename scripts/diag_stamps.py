@@ -12,7 +12,7 @@ rs.render(); rs.sync()
 total, walk, test, witers, batches, steps, waves, items = rs.debug_counters(True)
 unroll = int(os.environ.get("UNROLL", "5"))  # RT_WF_BLIND
 print(f"waves {waves}: cycles/wave {total / waves:.0f} = walk {walk / waves:.0f} ({witers / waves:.1f} loop heads x {unroll} steps, "
-      f"{walk / max(witers * unroll, 1):.0f} cyc per step, lane utilisation {steps / max(witers * unroll * 64, 1):.2f}) "
+      f"{walk / max(witers * unroll, 1):.0f} cyc per step) "
       f"+ test {test / waves:.0f} ({batches / waves:.1f} batches, {test / max(batches, 1):.0f} cyc each, {items / max(batches, 1):.1f} items per batch) "
-      f"+ rest {(total - walk - test) / waves:.0f};  lane-steps {steps}")
+      f"+ rest {(total - walk - test) / waves:.0f};  before the walk (staging, planning, cuts) {steps / waves:.0f} per wave pass")
 rs.close()
