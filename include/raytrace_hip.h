@@ -311,7 +311,8 @@ typedef struct rtHipMesh {
     const cl_float3 *points;
     cl_uint polygonCount;
     const cl_int *polygons;           /* 4 indices a,b,c,d per polygon; c == d marks a triangle (render.cpp:736) */
-    const cl_float3 *cornerNormals;   /* optional, 4 per polygon (a,b,c,d), any length; NULL = face normal turned to the camera (:754-771) */
+    const cl_float3 *cornerNormals;   /* optional, 4 per polygon (a,b,c,d), any length; NULL -- or a zero vector at a corner of the triangle -- =
+                                       * face normal turned to the camera (:754-771) */
     const cl_float2 *cornerUv;        /* optional, 4 per polygon; NULL = (0,0),(0,1),(1,1) for every triangle (:956-963) */
     const cl_int *polygonMaterial;    /* optional, one id per polygon; NULL = -1, "no material" (:1098) */
 } rtHipMesh;
@@ -351,6 +352,46 @@ typedef struct rtHipMaterialSpec {
 int rtHipBakeMaterials(const rtHipMaterialSpec *materials, cl_uint materialCount, cl_uint2 *materialImageSize, cl_int *materialImageStart,
                        cl_uchar3 *textures, cl_uint texturesCapacity, cl_uint *texturesSize);
 
+/* FILE INPUT (rt_fileio.cpp).  The reference walks Cinema 4D's object tree (render.cpp:707-1003) and bakes C4D bitmaps
+ * (render.cpp:1136-1309); a host without Cinema 4D has files.
+ *
+ * rtHipObjRead: a Wavefront OBJ (v / vt / vn / f with triangles, quads and larger faces -- fanned --, negative indices, usemtl,
+ * mtllib) as ONE polygon object in rtHipMesh's shape: 4-float points, polygons a,b,c,d with c == d marking a triangle, and -- when
+ * any face carries them -- 4 corner normals / 4 corner UVs per polygon (zero where a face has none), one material id per polygon
+ * (-1 before the first usemtl).  The materials its MTL libraries define (paths relative to the OBJ) come back as rtHipObjMaterial:
+ * Kd = material colour, d / Tr = opacity, Ke = emission, refl = reflectance, and the channel image paths map_Kd (colour), map_refl
+ * (reflection), map_d (transparency), map_bump / bump (bump), map_Ke (luminance).  Arrays are malloc'ed: rtHipObjFree.
+ * Returns 0, -1 null argument, -2 malformed file, -3 out of memory, -4 cannot open. */
+typedef struct rtHipObjMaterial {
+    char name[64];
+    cl_float kd[3];            /* Kd (default 1 1 1) */
+    cl_float ke[3]; cl_int hasKe;
+    cl_float dissolve;         /* d, or 1 - Tr (default 1 = opaque) */
+    cl_float reflect; cl_int hasReflect;
+    char map[5][256];          /* image path per channel in the reference's order (colour, reflection, transparency, bump, luminance); "" = none */
+} rtHipObjMaterial;
+typedef struct rtHipObjData {
+    cl_uint pointCount; cl_float3 *points;
+    cl_uint polygonCount; cl_int *polygons; cl_float3 *cornerNormals; cl_float2 *cornerUv; cl_int *polygonMaterial;
+    cl_uint materialCount; rtHipObjMaterial *materials;
+} rtHipObjData;
+int  rtHipObjRead(const char *path, rtHipObjData *out);
+void rtHipObjFree(rtHipObjData *data);
+
+/* An image file as rtHipChannelSpec::pixels: binary or plain PPM (P6 / P3, maxval <= 255, scaled to 255) or an uncompressed 24 / 32-bit
+ * BMP -> width*height texels of 4 bytes (r, g, b, 0), top row first, malloc'ed (rtHipFree).  Returns 0, -1 null argument, -2 not
+ * such a file, -3 out of memory, -4 cannot open. */
+int rtHipImageRead(const char *path, cl_uint *width, cl_uint *height, cl_uchar3 **pixels);
+
+/* ShdProjectPoint (render.cpp:495-673): the UV a point gets from a texture tag's projection when its polygon has no UVW tag
+ * (render.cpp:917-945).  Same operations in the same order in double (the SDK's Float), results cast to float as at :940-941;
+ * RT_PROJ_FRONTAL / RT_PROJ_UVW are not handled by the reference either (uv is left as it is).  The numbering is the Cinema 4D
+ * SDK's (c4d_shader.h: P_SPHERICAL ...; not in this checkout).  Returns 1 when the texture tiles or uv lies in [0,1]^2, else 0. */
+enum { RT_PROJ_SPHERICAL = 0, RT_PROJ_CYLINDRICAL = 1, RT_PROJ_FLAT = 2, RT_PROJ_CUBIC = 3, RT_PROJ_FRONTAL = 4, RT_PROJ_SPATIAL = 5,
+       RT_PROJ_UVW = 6, RT_PROJ_SHRINKWRAP = 7, RT_PROJ_VOLUMESHADER = 10 };
+int rtHipProjectUv(int projection, const cl_float point[3], const cl_float normal[3], cl_float offsetX, cl_float offsetY, cl_float lengthX,
+                   cl_float lengthY, int tile, cl_float uv[2]);
+
 /* u16 planes -> interleaved 8-bit RGB, top row first: value / 256 (render.cpp:1379-1382).  lowByteCompat != 0 keeps the LOW
  * byte instead, which is what the reference's debug BMP does (writebmp.cpp:136-141, a truncation bug). */
 void rtHipPlanesToRgb8(cl_uint width, cl_uint height, const cl_ushort *red, const cl_ushort *green, const cl_ushort *blue,
@@ -378,7 +419,7 @@ int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint in
 /* TEST / TUNING ONLY.  The library reads no environment variables (a plugin host's environment must not be able to slow frames
  * down, make them redo themselves or fail); every tuning value and every fault injector of the tests is set here, process-wide,
  * and applies to scenes built afterwards.  Keys (rt_api.cpp, struct Tuning): "reset" (all defaults), "stage_mb", "extra_factor",
- * "state_mb", "groups", "lookahead", "seg0".."seg4", "seg_rays0".."seg_rays3", "fast_quotient", "spin_limit", "append_rays",
+ * "state_mb", "groups", "lookahead", "seg0".."seg4", "seg_rays0".."seg_rays3", "fast_quotient", "spin_limit", "append_rays", "ordered_first", "extra_factor",
  * "slice_rays", "small_slices", "group_rays", "blocking", "batch_plan", "pipeline", "timing", "cache", and the test hooks "plan_rounds",
  * "plan_grid_tiny", "virtual_devices".  Returns 0, -1 for an unknown key. */
 int rtHipTune(const char *key, double value);

@@ -15,6 +15,11 @@ import numpy as np
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m opencl_render_amd", description=__doc__.splitlines()[0])
     ap.add_argument("--scene", choices=["room", "soup"], default="room", help="demo room (meshes through the front-end) or a seeded triangle soup")
+    ap.add_argument("--obj", help="render this Wavefront OBJ (its MTL libraries and PPM / BMP textures are read too) instead of a demo scene")
+    ap.add_argument("--eye", type=float, nargs=3, default=None, help="--obj: camera position (default: in front of the model's bounding box)")
+    ap.add_argument("--look-at", type=float, nargs=3, default=None, help="--obj: point the camera looks at (default: the bounding box's centre)")
+    ap.add_argument("--fov", type=float, default=50.0, help="--obj: horizontal field of view in degrees")
+    ap.add_argument("--light-dir", type=float, nargs=3, default=(0.3, -0.8, 0.5), help="--obj: direction of the one distant light")
     ap.add_argument("--width", type=int, default=1024)   # the dialog's defaults (render.cpp:176-182)
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--samples", type=int, default=100)
@@ -31,7 +36,15 @@ def main(argv=None):
     if not (1 <= args.device < len(names)):
         sys.exit(f"--device {args.device}: choose 1..{len(names) - 1} ({names[1:]})")
     t0 = time.perf_counter()
-    if args.scene == "room":
+    if args.obj:
+        mesh, materials = frontend.read_obj(args.obj)
+        lo, hi = mesh.points.min(axis=0), mesh.points.max(axis=0)
+        centre, size = (lo + hi) / 2, float(np.linalg.norm(hi - lo)) or 1.0
+        look_at = np.asarray(args.look_at, np.float32) if args.look_at else centre
+        eye = np.asarray(args.eye, np.float32) if args.eye else centre + np.float32([0.35, 0.25, -1.0]) * size
+        sc = frontend.scene_from_meshes([mesh], materials, [dict(type=scene.LIGHT_DISTANT, dir=tuple(args.light_dir))], eye, look_at, (0, 1, 0),
+                                        np.radians(args.fov), args.width, args.height, samples=args.samples, name=args.obj)
+    elif args.scene == "room":
         sc = demo.room_scene(args.width, args.height, samples=args.samples)
     else:
         sc = scene.make_soup(args.width, args.height, args.triangles, 0.02, samples=args.samples)

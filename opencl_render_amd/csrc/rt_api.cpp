@@ -72,6 +72,7 @@ int fail(const char *fmt, ...)
 // afterwards.
 struct Tuning {
     uint32_t stageMb = 32;          // size of each of the two pinned staging buffers of an upload
+    uint32_t extraFactor = 6;       // region B of the entry arrays (further segments of cut rays), in units of the path capacity
     uint64_t stateMb = 0;           // path-state budget per sample batch (0 = 24 GB, never more than a third of free memory); tests force several batches
     uint32_t groups = 1;            // concurrent tile groups per instance (measured: no gain once rays are cut into segments)
     uint32_t lookAhead = 1;         // 0: one ray in flight per path
@@ -79,7 +80,8 @@ struct Tuning {
     uint32_t segRays[4] = { 700000u, 300000u, 100000u, 30000u };
     uint32_t fastQuotient = 1;
     uint32_t spinLimit = 16384;     // a ray makes at most 766 cell visits = 154 walk phases; lowered by the test of the guard's error path
-    uint32_t appendRays = 300000;   // rounds with fewer rays are not ordered: the trace kernel plans and cuts their rays itself (RtRoundMode)
+    uint32_t appendRays = 300000;   // later rounds with fewer rays are not ordered: the trace kernel plans and cuts their rays itself (RtRoundMode)
+    uint32_t orderedFirst = 1;      // 0: round 1 follows the same rule (tests: the trace kernel's planning on dense rounds)
     uint32_t sliceRays = 0;         // rounds with fewer rays use smallSlices queue slices per kind instead of RT_WF_SHARDS (off: a round's appends want
                                     // many counters -- 16 slices cost the logic kernel of a 58 k-ray round 17 us -- and the trace kernel packs its pieces anyway)
     uint32_t smallSlices = 16;
@@ -213,7 +215,8 @@ struct rtHipScene {
         // launch plan (render_wavefront): what the last discovery frame needed
         uint32_t roundsNeeded = 0;
         // per round: rays (entries in region A), the longest queue slice, entries in region B -- the maximum over the watched batches
-        struct RoundPlan { uint32_t rays = 0; };
+        // rays of the round, and -- an ordered round -- the further segments of its cut rays under the cut it was logged with
+        struct RoundPlan { uint32_t rays = 0, extra = 0, extraSegLen = 0; };
         uint4 *hostLog = nullptr;       // pinned + mapped: RtWavefront::roundLog, written by the kernels, read by the host after a sync
         RoundPlan plan[RT_WF_ROUND_LOG], planNext[RT_WF_ROUND_LOG];
         std::vector<RtRoundMode> modes; // how the rounds of the batch being issued are laid out (modes[r] is decided when logic(r-1) is launched)
@@ -550,9 +553,11 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
     HIP_OK(hipGetDeviceProperties(&prop, sc->device));
     const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     const uint64_t pix = (uint64_t)nt * RT_TILE_PIXELS;
+    const uint32_t extraFactor = std::min<uint32_t>(std::max<uint32_t>(T.extraFactor, 1u), 16u);
     // per path: rng, meta, outc, ring, shadow-wait state, look-ahead answer + slot, primary hit, finished colour; per queue entry (two per
-    // path): path id, answer and the 64-byte entry per round parity, rank, class, sorted position
-    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 16 + 2 * (2 * (4 + 8 + 64) + 4 + 2 + 4);
+    // path): path id and answer per round parity; per entry (2 + extraFactor per path): the 64-byte entry per round parity, rank, class,
+    // sorted position
+    const uint64_t perPath = 8 + 16 + 16 + (uint64_t)RT_RING * 48 + 3 * 16 + 8 + 4 + 16 + 16 + 2 * 2 * (4 + 8) + (uint64_t)(2 + extraFactor) * (2 * 64 + 4 + 2 + 4);
     // bytes of path state per sample batch: more samples per batch = fewer, fuller rounds (S=4 at 1080p: 5.0 ms with one
     // sample per batch, 4.5 ms with all four); 24 GB of the 288 GB, and never more than a third of what is free
     uint64_t budget = 24ull << 30;
@@ -589,7 +594,10 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         Wf.shardCap = (uint32_t)shardCap;
         Wf.lookAhead = T.lookAhead ? 1u : 0u;
         const uint64_t qcap = 2 * cap; // queue entries: up to two rays in flight per path
-        const uint64_t ecap = qcap;
+        const uint64_t extraCap = (uint64_t)extraFactor * cap; // room for the further segments of cut rays (a wave that finds it full leaves its rays whole)
+        const uint64_t ecap = qcap + extraCap;
+        if (ecap > 0xfffffff0ull) return fail("tile set too large for one batch");
+        Wf.extraCap = (uint32_t)extraCap;
         Wf.sampleBase = 0; Wf.samplesInBatch = (uint32_t)sb;
         if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
             sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
@@ -683,10 +691,12 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
 
 // How a round with `rays` rays is laid out (RtRoundMode, rt_device.h): big rounds are ordered by predicted walk length and spread
 // their appends over all queue slices, small ones are cut into segments and keep their entries dense.
-RtRoundMode mode_for(const Tuning &T, uint64_t rays, uint32_t slicesBefore)
+RtRoundMode mode_for(const Tuning &T, uint32_t round, uint64_t rays, uint32_t slicesBefore)
 {
     RtRoundMode m;
-    m.ordered = rays >= T.appendRays ? 1u : 0u;
+    // planned where the rays are made (and ordered) when most paths make one: the round behind the primary hits, and any big round
+    m.ordered = (round <= 1u || rays >= T.appendRays) ? 1u : 0u;
+    if (T.orderedFirst == 0u && rays < T.appendRays) m.ordered = 0u;
     m.segLen = rays >= T.segRays[0] ? T.segLen[0] : (rays >= T.segRays[1] ? T.segLen[1] : (rays >= T.segRays[2] ? T.segLen[2] : (rays >= T.segRays[3] ? T.segLen[3] : T.segLen[4])));
     if (m.segLen < 1u) m.segLen = 1u;
     uint32_t small = T.smallSlices;
@@ -754,7 +764,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
             uint64_t rays = G.guessRays;
             if (planned) rays = r < RT_WF_ROUND_LOG ? G.plan[r].rays : 0;
             else G.guessRays = std::max<uint64_t>(G.guessRays / 4, 1); // (watched: a round is assumed to hold a quarter of the one before)
-            G.modes.resize(r + 1, mode_for(T, rays, before));
+            G.modes.resize(r + 1, mode_for(T, r, rays, before));
         }
         return G.modes[r];
     };
@@ -765,8 +775,11 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
         if (!planned || r >= RT_WF_ROUND_LOG) return (uint32_t)std::min<uint64_t>(worst, 0x7fffffffu);
         if (T.planGridTiny) return 1;
         // the same frame gave this many rays last time: a tenth more plus a few, never more than the worst case
+        // (an ordered round's further segments: as many as last time if the cut is the same -- a watched frame guesses the round's size
+        // and with it the cut -- and at most RT_WF_MAXSEG - 1 per ray whatever the cut)
         const uint64_t rays = G.plan[r].rays;
-        const uint64_t want = m.ordered ? (rays * 11 / 10 + 255) / 256 + 8 : (rays * 11 / 10 + m.groupRays - 1) / m.groupRays + 2ull * m.slices + 8;
+        const uint64_t extra = std::min<uint64_t>(G.wf.extraCap, G.plan[r].extraSegLen == m.segLen ? G.plan[r].extra : (m.segLen >= 4096u ? 0 : rays * 11));
+        const uint64_t want = m.ordered ? ((rays + extra) * 11 / 10 + 255) / 256 + 8 : (rays * 11 / 10 + m.groupRays - 1) / m.groupRays + 2ull * m.slices + 8;
         return (uint32_t)std::max<uint64_t>(std::min<uint64_t>(want, worst), 1);
     };
     auto issue_round = [&](rtHipScene::Group &G, hipStream_t on) -> int {
@@ -842,7 +855,11 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
                 if (G.rounds > RT_WF_ROUND_LOG) needed = G.rounds;
                 G.roundsNeeded = std::max(G.roundsNeeded, needed);
                 for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) {
-                    G.planNext[r].rays = std::max(G.planNext[r].rays, log[r].x); // the maximum over the watched batches
+                    rtHipScene::Group::RoundPlan &N = G.planNext[r]; // the maximum over the watched batches
+                    N.rays = std::max(N.rays, log[r].x);
+                    const uint32_t seg = r < G.modes.size() ? G.modes[r].segLen : 4096u;
+                    if (N.extraSegLen != seg && N.extraSegLen != 0u) N.extraSegLen = 0xffffffffu; // (batches cut differently: no figure)
+                    else { N.extraSegLen = seg; N.extra = std::max(N.extra, log[r].z); }
                 }
             } else anyPlannedBatch = true;
             rounds = std::max<uint64_t>(rounds, G.rounds);
@@ -862,7 +879,7 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
                 need = std::max(need, G.roundsNeeded);
                 for (uint32_t r = 0; r < RT_WF_ROUND_LOG; ++r) {
                     G.plan[r] = G.planNext[r];
-                    G.plan[r].rays += G.plan[r].rays / 10;
+                    G.plan[r].rays += G.plan[r].rays / 10; G.plan[r].extra += G.plan[r].extra / 10;
                 }
             }
             planRounds = need + 1; // (one spare round: a later batch's deepest path may go one bounce further)
@@ -1334,10 +1351,10 @@ int rtHipTune(const char *key, double value)
     const uint32_t u = value < 0 ? 0u : (value > 4294967295.0 ? 0xffffffffu : (uint32_t)value);
     if (k == "reset") { T = Tuning(); return 0; }
     struct { const char *name; uint32_t *field; } table[] = {
-        { "stage_mb", &T.stageMb }, { "groups", &T.groups }, { "lookahead", &T.lookAhead },
+        { "stage_mb", &T.stageMb }, { "extra_factor", &T.extraFactor }, { "groups", &T.groups }, { "lookahead", &T.lookAhead },
         { "seg0", &T.segLen[0] }, { "seg1", &T.segLen[1] }, { "seg2", &T.segLen[2] }, { "seg3", &T.segLen[3] }, { "seg4", &T.segLen[4] },
         { "seg_rays0", &T.segRays[0] }, { "seg_rays1", &T.segRays[1] }, { "seg_rays2", &T.segRays[2] }, { "seg_rays3", &T.segRays[3] },
-        { "fast_quotient", &T.fastQuotient }, { "spin_limit", &T.spinLimit }, { "append_rays", &T.appendRays }, { "slice_rays", &T.sliceRays },
+        { "fast_quotient", &T.fastQuotient }, { "spin_limit", &T.spinLimit }, { "append_rays", &T.appendRays }, { "ordered_first", &T.orderedFirst }, { "slice_rays", &T.sliceRays },
         { "small_slices", &T.smallSlices }, { "group_rays", &T.groupRays }, { "blocking", &T.blocking }, { "plan_rounds", &T.planRounds }, { "plan_grid_tiny", &T.planGridTiny },
         { "pipeline", &T.pipeline }, { "timing", &T.timing }, { "virtual_devices", &T.virtualDevices }, { "cache", &T.cache }, { "batch_plan", &T.batchPlan },
     };

@@ -129,17 +129,19 @@ struct RtDevScene {
 // scatter(r) and trace(r) read it, logic(r) zeroes set (r + 2) % 3 for logic(r+1)
 #define RT_WF_CTL_COUNTS 0                                   // [RT_WF_QSHARDS] queue lengths
 #define RT_WF_CTL_HIST RT_WF_QSHARDS                         // [RT_WF_SORT_COPIES][RT_WF_SORT_BINS] entries per (copy, bin) of an ordered round
-#define RT_WF_CTL_TOTAL (RT_WF_CTL_HIST + RT_WF_SORT_COPIES * RT_WF_SORT_BINS) // ordered round: entries in sortedIdx (written by wf_scatter_kernel)
-#define RT_WF_CTL_WORDS (RT_WF_CTL_TOTAL + 4)                // (multiple of 4)
+#define RT_WF_CTL_EXTRA (RT_WF_CTL_HIST + RT_WF_SORT_COPIES * RT_WF_SORT_BINS) // ordered round: entries in region B (further segments of cut rays)
+#define RT_WF_CTL_TOTAL (RT_WF_CTL_EXTRA + 1)                // ordered round: entries in sortedIdx (written by wf_scatter_kernel)
+#define RT_WF_CTL_WORDS (RT_WF_CTL_TOTAL + 3)                // (multiple of 4)
 
 // How a round's entries are laid out and handed to the trace kernel.  Decided by the HOST before the round exists (from the launch
 // plan the same frame left behind, or from a guess in a watched frame) and passed to the kernels as an argument: a wrong guess
 // costs time, never correctness.
 struct RtRoundMode {
-    uint32_t ordered;   // 1: many rays -- the logic kernel writes complete trace entries and counts their walk-length classes, wf_scatter_kernel
-                        // places them longest first, rays are never cut; 0: few rays -- the logic kernel writes the rays, the trace kernel's
-                        // workgroups plan them, cut them into segments and trace those, in queue order
-    uint32_t segLen;    // round that is not ordered: aimed-at cell visits per segment (>= 4096: rays are never cut)
+    uint32_t ordered;   // 1: a round most paths spawn a ray for (the first one, or any big one) -- the logic kernel writes complete trace entries,
+                        // cuts long rays into segments and counts the entries' walk-length classes, wf_scatter_kernel places them longest
+                        // first; 0: a round few paths spawn a ray for -- the logic kernel writes the rays, the trace kernel's workgroups plan
+                        // them, cut them into segments and trace those, in queue order
+    uint32_t segLen;    // aimed-at cell visits per segment (>= 4096: rays are never cut)
     uint32_t groupRays; // round that is not ordered: rays per workgroup of the trace kernel (1..64; about 256 / expected segments per ray)
     uint32_t slices;    // queue slices in use per kind (power of two <= RT_WF_SHARDS, never more than the round before): a big round
                         // spreads its appends over 256 counters, a small one keeps its entries in a few dense stretches
@@ -153,7 +155,7 @@ struct RtWavefront {
     uint32_t fastQuotient;   // 1: waves whose rays all have tame exponents skip the scaling / fix-up instructions of the quotients
     uint32_t spinLimit;      // walk phases a wave of wf_trace_kernel may run before it gives up and raises RT_WF_ERR_SPIN (default 16384)
     uint32_t *hostStatus;    // pinned HOST words mapped into the device (RT_WF_STATUS_*): written by kernels, read by the host after a sync
-    uint4 *roundLog;         // [RT_WF_ROUND_LOG] per round: x rays, y longest queue slice
+    uint4 *roundLog;         // [RT_WF_ROUND_LOG] per round: x rays, y longest queue slice, z entries in region B
     // per-path state, indexed by path id
     unsigned long long *rng; // generator state (raytrace_opencl.c:474-481), already moved past the current hit's light draws
     unsigned long long *rngL; // lightCount > 1 only: where the current hit's NEXT light set-up draws from
@@ -169,14 +171,17 @@ struct RtWavefront {
     float4 *shFace;          // xyz: the face[] entry that :647 will select (the other one is dead); w: 1 if front facing
     float4 *shAtt;           // shadow attenuation so far (only once a transparent occluder was met, :616-625)
     float4 *shN;             // lightCount > 1 only: shading normal for the next light's set-up (the hit point rides in the entry)
-    // Trace entries, 64 bytes: {q, cell, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz, -} -- the ray and, in an ordered round,
-    // its DDA start state (start / end cell, the three crossing parameters), computed by the kernel that spawns the ray; a round that
-    // is not ordered carries the ray only (excluded, tmin, o, tmax, d) and has its start states made by the trace kernel.
+    // Trace entries, 64 bytes: {q, cell | class << 24, endCell, excluded} {dx,dy,dz,tmin} {o.xyz,tmax} {d.xyz, rank in wave | segment << 24}
+    // -- the ray and, in an ordered round, its DDA start state (start / end cell, the three crossing parameters), computed by the
+    // kernel that spawns the ray; a round that is not ordered carries the ray only (excluded, tmin, o, tmax, d) and has its start
+    // states made by the trace kernel.  A long ray of an ordered round with few rays becomes several entries (SEGMENTS,
+    // rt_wavefront.hip): segment 0 sits at the ray's queue index (region A, [0, 2*capacity)), further segments are packed into
+    // region B ([2*capacity, 2*capacity + extraCap)).
     // Queue slice s of a round with `slices` slices per kind holds entries [s*sliceCap, s*sliceCap + counts[s]) with sliceCap =
     // capacity / slices for the main entries and the same range + capacity for the look-ahead entries (counts[RT_WF_SHARDS + s]);
     // a path born into shard b appends to slice b % slices, so appends hit up to 512 different counters (a single address sustains
     // only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shards.
-    uint4 *ent[2];             // [2*capacity][4], by round parity
+    uint4 *ent[2];             // [2*capacity + extraCap][4], by round parity
     uint32_t *pathOf[2];       // [2*capacity] path id of queue entry q, by round parity
     unsigned long long *hitKey[2]; // [2*capacity] per ray: segment << 32 | pair index of the hit in the lowest segment that has one; all ones = no hit
     uint4 *res;                // round 0 only: the primary hit of the path -- triangle, t, l1, l2 (float bits)
@@ -184,9 +189,10 @@ struct RtWavefront {
     uint32_t *ctl;             // [3][RT_WF_CTL_WORDS] per-round control words (RT_WF_CTL_*), zeroed in-stream by the logic kernel
     // An ORDERED round: entries keyed by the PREDICTED number of cell visits (exact for rays that hit nothing), counting-sorted
     // longest first, so that a wave holds rays of similar length and the longest walks of the round start first.
-    uint32_t *sortedIdx;       // [2*capacity] index into ent of the entry at each sorted position
-    uint32_t *sortRank;        // [2*capacity] rank of the entry inside its (bin, copy) class
-    uint16_t *sortTag;         // [2*capacity] the class: bin | copy << 6 (what wf_scatter_kernel needs of an entry, 6 bytes instead of a 64-byte line)
+    uint32_t *sortedIdx;       // [2*capacity + extraCap] index into ent of the entry at each sorted position
+    uint32_t *sortRank;        // [2*capacity + extraCap] rank of the entry inside its (bin, copy) class; 0xffffffff = an unused reservation
+    uint16_t *sortTag;         // [2*capacity + extraCap] the class: bin | copy << 6 (what wf_scatter_kernel needs of an entry, 6 bytes instead of a 64-byte line)
+    uint32_t extraCap;         // capacity of region B (multiple of 256)
     float4 *sampleOut;         // [capacity] finished colour per output slot
 };
 

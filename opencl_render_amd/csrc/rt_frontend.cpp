@@ -108,7 +108,13 @@ int rtHipMeshFill(const rtHipMesh *meshes, cl_uint meshCount, const cl_float cam
                 const int *c = corners[half];
                 for (int k = 0; k < 3; ++k) triIndex[tCursor].s[k] = (cl_int)firstVertex + p[c[k]];
                 triIndex[tCursor].s[3] = 0;
-                if (M.cornerNormals) { // :740-752 -- per-corner normals, normalised in double, then rounded to float
+                bool haveNormals = M.cornerNormals != nullptr;
+                if (haveNormals) // (a polygon with a zero corner normal -- an OBJ face without vn among faces with -- counts as one without normals)
+                    for (int k = 0; k < 3; ++k) {
+                        const cl_float3 &n = M.cornerNormals[4 * (size_t)i + c[k]];
+                        if (n.s[0] == 0.f && n.s[1] == 0.f && n.s[2] == 0.f) haveNormals = false;
+                    }
+                if (haveNormals) { // :740-752 -- per-corner normals, normalised in double, then rounded to float
                     for (int k = 0; k < 3; ++k) {
                         const cl_float3 &n = M.cornerNormals[4 * (size_t)i + c[k]];
                         const double x = n.s[0], y = n.s[1], z = n.s[2];

@@ -294,16 +294,29 @@ struct DdaState { uint32_t cell; float dx, dy, dz; };
 
 // One axis of the state at parameter tau: c0 = cell coordinate of the walk's start, returns the coordinate after all
 // crossings with T <= tau and, in `head`, the parameter of the next crossing.  `limit` = crossings that stay inside the grid.
-__device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t c0, float oa, float da, float tau, float &head)
+// `lut` / `lutScale` (optional): this axis' 256 cell estimates and 256 / box width (RtDevScene::cellLut) -- the guess then costs one
+// table read instead of the eight dependent reads of a plane search, unless the table is coarse where the point lies.
+__device__ __forceinline__ uint32_t axis_state_at(const float *planes, uint32_t c0, float oa, float da, float tau, float &head,
+                                                  const uint8_t *lut = nullptr, float lutScale = 0.f)
 {
     const bool pos = (0.f <= da);
     const int limit = pos ? (int)(RT_GRID_DIV - 1 - c0) : (int)c0; // the crossing after these leaves the grid (tau is before it)
     // guess from the position (the plane search of GetBoxAddress), then settle it with the exact quotients
     const float p = oa + tau * da;
     int g = 0;
+    bool search = true;
+    if (lut) {
+        const int i = min(255, max(0, (int)((p - planes[0]) * lutScale)));
+        const int a = lut[max(i - 1, 0)], b = lut[min(i + 1, 255)];
+        g = lut[i];
+        search = b - a > 4; // (more than a few cells in three table steps: the settling loops below would walk them one by one)
+    }
+    if (search) {
+        g = 0;
 #pragma unroll
-    for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2)
-        if (planes[g + div] < p) g += div;
+        for (int div = RT_GRID_DIV / 2; div >= 1; div /= 2)
+            if (planes[g + div] < p) g += div;
+    }
     int m = pos ? g - (int)c0 : (int)c0 - g;
     m = m < 0 ? 0 : (m > limit ? limit : m);
     // crossing number k (1-based) is plane c0+k going up, c0-k+1 going down
@@ -456,6 +469,7 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
     // an ordered round's classes, per wave: entries of this wave per walk-length class, then where the class's ranks of this wave start
     __shared__ uint32_t waveHist[ORDERED ? 4 : 1][RT_WF_SORT_BINS], waveBase[ORDERED ? 4 : 1][RT_WF_SORT_BINS];
     __shared__ uint8_t cellLut[ORDERED ? 3 * 256 : 4];
+    __shared__ uint8_t itemOwner[ORDERED ? 4 : 1][64 * (RT_WF_MAXSEG - 1)]; // per wave: which lane's ray the i-th further segment belongs to
     __shared__ float lutScale[3];
     static_assert(RT_WF_SORT_BINS == 64, "one class per lane");
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
@@ -865,12 +879,20 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
         slotLa += W.capacity + outShard * sliceCapOut;
         asm volatile("" : "+v"(a), "+v"(slot), "+v"(slotLa)); // (addresses made here, not carried across the state machine)
         if (slot != 0xfffffff0u) DG(8);
-        // The rays of the next round go to their queue slots now.  An ORDERED round (many rays, nearly every lane has one): as complete
-        // trace entries -- DDA start state and walk-length class -- so that nothing stands between this kernel and the walk but the
-        // placing of the classes.  Any other round: the ray alone; wf_trace_kernel<false> plans and cuts it (stage "trace entries").
-        uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0; // ordered round: the entry's class and its rank inside this wave
+        // The rays of the next round go to their queue slots now.  An ORDERED round (most lanes have one): as complete trace entries --
+        // DDA start state, segments, walk-length class -- so that nothing stands between this kernel and the walk but the placing of
+        // the classes.  Any other round: the ray alone; wf_trace_kernel<false> plans and cuts it (stage "trace entries").
+        uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0; // ordered round: segment 0's class and its rank inside this wave
+        uint32_t itemsM = 0, itemsL = 0, itemsAtM = 0, itemsAtL = 0; // further segments of this wave's main / look-ahead rays: how many, and where in region B
         uint32_t cellM = 0;
         const uint32_t copy = waveId % RT_WF_SORT_COPIES;
+        // walk-length class of an entry that will make v cell visits if it hits nothing (scheduling only).  Two scales: segments of a
+        // finely cut round differ by a few visits, uncut rays by hundreds; class 0 = longest
+        auto visit_class = [](uint32_t v) -> uint32_t {
+            if ((int)v < 1) v = 1;
+            if (v > 767u) v = 767u;
+            return (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+        };
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
             const bool has = which ? emitLa : emit;
@@ -878,33 +900,133 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
             const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
             const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
             const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
-            if (!has) continue;
-            W.pathOf[outq][mine] = a;
-            W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
-            if (which) W.laSlot[a] = mine;
             uint4 *e = W.ent[outq] + 4 * (size_t)mine;
-            if (ORDERED) {
+            if (has) {
+                W.pathOf[outq][mine] = a;
+                W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
+                if (which) W.laSlot[a] = mine;
+                e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+            }
+            if (!ORDERED) {
+                if (has) {
+                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
+                    reinterpret_cast<uint32_t *>(e)[7] = __float_as_uint(tmin);
+                    e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
+                }
+                continue;
+            }
+            EntryPlan plan;
+            plan.visits = 1; plan.endCell = 0xffffffffu; plan.te = RT_INF;
+            plan.start.cell = 0; plan.start.dx = 0.f; plan.start.dy = 0.f; plan.start.dz = 0.f;
+            uint32_t nseg = 0;
+            if (has) {
                 // (a hit's look-ahead ray starts where its shadow ray starts: one plane search for the two -- when the start is the origin
                 // itself, tmin = 0, and lies inside the grid's box, so that BindInCube (:265-322) moves it for neither direction)
                 const bool sameStart = which && emit && lo3.x == ro.x && lo3.y == ro.y && lo3.z == ro.z && latmin == 0.f && rtmin == 0.f &&
                                        planes[0] <= o.x && o.x <= planes[RT_GRID_DIV] && planes[RT_GRID_DIV + 1] <= o.y && o.y <= planes[2 * RT_GRID_DIV + 1] &&
                                        planes[2 * (RT_GRID_DIV + 1)] <= o.z && o.z <= planes[3 * RT_GRID_DIV + 2];
-                const EntryPlan plan = plan_ray(planes, o, d, tmin, tmax, sameStart, cellM, cellLut, lutScale);
+                // (a round that is cut needs the exact far cell: the cut positions follow from the visit count)
+                plan = plan_ray(planes, o, d, tmin, tmax, sameStart, cellM, next.segLen >= 4096u ? cellLut : nullptr, lutScale);
                 if (!which) cellM = plan.start.cell;
-                // walk-length class (scheduling only).  Two scales: short walks differ by a few visits, long ones by hundreds; class 0 = longest
-                uint32_t v = plan.visits;
-                if (v > 767u) v = 767u;
-                const uint32_t bin = (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+                nseg = segments_of(plan, d, tmax, next.segLen);
+            }
+            uint32_t extraAt = 0, items = 0, before = 0;
+            // Room in region B for the further segments of this wave's rays: one atomic per wave that cuts anything.  A reservation is
+            // never undone (an add followed by a subtract is not atomic across waves: a later, smaller reservation could land inside
+            // the range the subtract gives back).  A count past extraCap just means "region B is full"; every reader clamps it.  The
+            // one wave whose range straddles the end owns [at, extraCap) and marks those slots empty; waves after it start past the
+            // end and own nothing.  No room, no cutting: the wave's rays stay whole.
+            if (__ballot(nseg > 1u) != 0ull) { // wave-uniform
+                const uint32_t extraMine = nseg > 1u ? nseg - 1u : 0u;
+                uint32_t incl = extraMine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(incl, off, 64);
+                    if ((int)lane >= off) incl += up;
+                }
+                items = (uint32_t)__shfl((int)incl, 63, 64);
+                before = incl - extraMine;
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(&ctlOut[RT_WF_CTL_EXTRA], items);
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                if ((uint64_t)base + items > (uint64_t)W.extraCap) {
+                    for (uint32_t i = base + lane; i < W.extraCap; i += 64) {
+                        W.ent[outq][4 * (size_t)(2u * W.capacity + i)].x = 0xffffffffu;
+                        W.sortRank[2u * W.capacity + i] = 0xffffffffu;
+                    }
+                    if (nseg > 1u) nseg = 1u;
+                    items = 0;
+                }
+                extraAt = 2u * W.capacity + base; // region B of the entry array starts after the 2*capacity queue slots
+                // who owns item i (= further segment before + j - 1 of lane `owner`)
+                for (uint32_t j = 1; j < nseg; ++j) itemOwner[wave][before + j - 1] = (uint8_t)lane;
+            }
+            if (which) { itemsL = items; itemsAtL = extraAt; } else { itemsM = items; itemsAtM = extraAt; }
+            const float ta = fminf(plan.start.dx, fminf(plan.start.dy, plan.start.dz));
+            const uint32_t perSeg = nseg ? (plan.visits + nseg - 1) / nseg : 1u;
+            if (has) { // segment 0, at the ray's queue index; where a cut ray's segment 0 ends is filled in by the lane that makes cut 1
+                float tau1;
+                const bool cut1 = nseg > 1u && cut_at(ta, plan.te, 1u, nseg, tau1);
+                const uint32_t bin = visit_class(cut1 ? perSeg : plan.visits);
                 const uint32_t rank = atomicAdd(&waveHist[wave][bin], 1u);
                 if (which) { binL = bin; rankL = rank; } else { binM = bin; rankM = rank; }
-                e[0] = make_uint4(mine, plan.start.cell, plan.endCell, excluded);
+                if (nseg > 1u) { // (.z comes from another lane: not written here, so that the two stores cannot meet)
+                    *reinterpret_cast<uint2 *>(e) = make_uint2(mine, plan.start.cell | (bin << 24));
+                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
+                } else e[0] = make_uint4(mine, plan.start.cell | (bin << 24), plan.endCell, excluded);
                 e[1] = make_uint4(__float_as_uint(plan.start.dx), __float_as_uint(plan.start.dy), __float_as_uint(plan.start.dz), __float_as_uint(tmin));
-            } else {
-                reinterpret_cast<uint32_t *>(e)[3] = excluded;
-                reinterpret_cast<uint32_t *>(e)[7] = __float_as_uint(tmin);
+                e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank); // (rank inside this wave's class for now; segment 0)
             }
-            e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
-            e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
+            if (items == 0u) continue; // wave-uniform
+            // The further segments, one per lane whoever's ray it is (a lane making its ray's up to 11 cuts one after the other while the
+            // wave's other lanes wait was 40 % of a chunk's time).  Segment k goes from the walk's state at tau_k to the start cell of
+            // segment k + 1; the cuts that exist are a prefix of 1 .. nseg - 1 (cut_at), so every lane can tell from k alone whether cut
+            // k and cut k + 1 exist, and writes where the segment BEFORE its own ends.
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i0 = 0; i0 < items; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool liveItem = i < items;
+                const uint32_t owner = liveItem ? itemOwner[wave][i] : 0u;
+                const uint32_t k = i - (uint32_t)__shfl((int)before, owner, 64) + 1u; // this lane makes cut k of `owner`'s ray
+                const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+                const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+                const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64), pta = __shfl(ta, owner, 64), pte = __shfl(plan.te, owner, 64);
+                const uint32_t pexcl = __shfl(excluded, owner, 64), pmine = __shfl(mine, owner, 64), pcell = __shfl(plan.start.cell, owner, 64);
+                const uint32_t pnseg = __shfl(nseg, owner, 64), pvisits = __shfl(plan.visits, owner, 64), pend = __shfl(plan.endCell, owner, 64);
+                if (!liveItem) continue;
+                const uint32_t at = extraAt + i; // entry of segment k
+                float tau, tauNext;
+                const bool cut = cut_at(pta, pte, k, pnseg, tau);
+                const bool cutNext = k + 1u < pnseg && cut_at(pta, pte, k + 1u, pnseg, tauNext);
+                uint32_t *prev = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)(k == 1u ? pmine : at - 1u));
+                uint32_t *self = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)at);
+                if (!cut) { // rounding left no room for this cut: the segment before runs to the ray's end, this one does not exist
+                    prev[2] = pend;
+                    self[0] = 0xffffffffu;
+                    W.sortRank[at] = 0xffffffffu;
+                    continue;
+                }
+                DdaState st;
+                // (counting the crossings with T <= tau from the ray's start cell: the state does not depend on where counting begins)
+                const uint32_t nx = axis_state_at(planes, pcell & 255u, po.x, pd.x, tau, st.dx, cellLut, lutScale[0]);
+                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (pcell >> 8) & 255u, po.y, pd.y, tau, st.dy, cellLut + 256, lutScale[1]);
+                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), pcell >> 16, po.z, pd.z, tau, st.dz, cellLut + 512, lutScale[2]);
+                st.cell = nx | (ny << 8) | (nz << 16);
+                prev[2] = st.cell; // the segment before ends where this one starts
+                const uint32_t per = (pvisits + pnseg - 1) / pnseg;
+                const uint32_t bin = visit_class(cutNext ? per : pvisits - per * k);
+                const uint32_t rank = atomicAdd(&waveHist[wave][bin], 1u);
+                *reinterpret_cast<uint2 *>(self) = make_uint2(pmine, st.cell | (bin << 24));
+                self[3] = pexcl;
+                if (!cutNext) self[2] = pend; // the ray's last segment
+                uint4 *se = reinterpret_cast<uint4 *>(self);
+                se[1] = make_uint4(__float_as_uint(st.dx), __float_as_uint(st.dy), __float_as_uint(st.dz), __float_as_uint(ptmin));
+                se[2] = make_uint4(__float_as_uint(po.x), __float_as_uint(po.y), __float_as_uint(po.z), __float_as_uint(ptmax));
+                se[3] = make_uint4(__float_as_uint(pd.x), __float_as_uint(pd.y), __float_as_uint(pd.z), rank | (k << 24));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // (itemOwner is rewritten for the look-ahead rays)
         }
         if (copy != 0xfffffff0u) DG(9);
         if (ORDERED) {
@@ -923,6 +1045,17 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
             __builtin_amdgcn_wave_barrier();
             if (emit) { W.sortRank[slot] = waveBase[wave][binM] + rankM; W.sortTag[slot] = (uint16_t)(binM | (copy << 6)); }
             if (emitLa) { W.sortRank[slotLa] = waveBase[wave][binL] + rankL; W.sortTag[slotLa] = (uint16_t)(binL | (copy << 6)); }
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) { // the further segments: class and rank in the wave are in the entries
+                const uint32_t items = which ? itemsL : itemsM, at0 = which ? itemsAtL : itemsAtM;
+                for (uint32_t i = lane; i < items; i += 64) {
+                    const uint4 *se = W.ent[outq] + 4 * (size_t)(at0 + i);
+                    if (se[0].x == 0xffffffffu) continue;
+                    const uint32_t bin = se[0].y >> 24;
+                    W.sortRank[at0 + i] = waveBase[wave][bin] + (se[3].w & 0xffffffu);
+                    W.sortTag[at0 + i] = (uint16_t)(bin | (copy << 6));
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier(); // (waveBase is overwritten by this wave's next chunk)
         }
@@ -959,8 +1092,9 @@ __device__ __forceinline__ uint32_t slice_count(const uint32_t *ctl, uint32_t sl
     return ctl[RT_WF_CTL_COUNTS + kind * RT_WF_SHARDS + shard];
 }
 
-// Work items: the used 256-entry blocks of the queue slices; a fixed grid takes them in turn.  The logic kernel left a rank inside
-// its (class, copy) and the class itself per entry; the classes' sizes are in the round's histogram.
+// Work items: the used 256-entry blocks of the queue slices (region A: segment 0 of every ray, in queue order), then the blocks of
+// region B (further segments, densely packed); a fixed grid takes them in turn.  The logic kernel left a rank inside its (class,
+// copy) and the class itself per entry; the classes' sizes are in the round's histogram.
 __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, const uint32_t round, const uint32_t slices)
 {
     __shared__ uint32_t base[RT_WF_SORT_BINS * RT_WF_SORT_COPIES];
@@ -990,16 +1124,28 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
     __syncthreads();
     const uint32_t usedBlocks = (max(max(longWave[0], longWave[1]), max(longWave[2], longWave[3])) + 255u) >> 8;
     const uint32_t itemsA = 2u * slices * usedBlocks;
-    for (uint32_t item = blockIdx.x; item < itemsA; item += gridDim.x) {
-        const uint32_t sl = item % (2u * slices);
-        const uint32_t local = (item / (2u * slices)) * 256 + threadIdx.x;
-        const bool valid = local < slice_count(ctl, slices, sl);
-        const uint32_t mine = slice_first(W, slices, sl) + local;
+    const uint32_t extra = min(ctl[RT_WF_CTL_EXTRA], W.extraCap); // the count runs past the capacity when region B filled up (wf_logic_kernel)
+    const uint32_t itemsB = (extra + 255u) >> 8;
+    for (uint32_t item = blockIdx.x; item < itemsA + itemsB; item += gridDim.x) {
+        uint32_t mine = 0;
+        bool valid = false;
+        if (item < itemsA) {
+            const uint32_t sl = item % (2u * slices);
+            const uint32_t local = (item / (2u * slices)) * 256 + threadIdx.x;
+            valid = local < slice_count(ctl, slices, sl);
+            mine = slice_first(W, slices, sl) + local;
+        } else {
+            const uint32_t local = (item - itemsA) * 256 + threadIdx.x;
+            valid = local < extra;
+            mine = 2u * W.capacity + local;
+        }
         if (valid) {
             // only the ORDER is written: the trace kernel gathers its 64-byte entries through it
             const uint32_t rank = W.sortRank[mine];
-            const uint32_t tag = W.sortTag[mine]; // bin | copy << 6
-            W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + rank] = mine;
+            if (rank != 0xffffffffu) { // not an unused reservation
+                const uint32_t tag = W.sortTag[mine]; // bin | copy << 6
+                W.sortedIdx[base[(tag & 63u) * RT_WF_SORT_COPIES + (tag >> 6)] + rank] = mine;
+            }
         }
     }
 }
@@ -1071,7 +1217,10 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     if (ORDERED) {
         const uint32_t total = ctl[RT_WF_CTL_TOTAL];
         const uint32_t blocksUsed = (total + 255u) >> 8;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && blocksUsed > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (round < RT_WF_ROUND_LOG) reinterpret_cast<uint32_t *>(W.roundLog + round)[2] = min(ctl[RT_WF_CTL_EXTRA], W.extraCap);
+            if (blocksUsed > gridDim.x) atomicOr(W.hostStatus + RT_WF_STATUS_ERROR, RT_WF_ERR_GRID);
+        }
         if (blockIdx.x >= blocksUsed) return; // whole workgroup beyond the entries
         const uint32_t at = blockIdx.x * 256 + threadIdx.x;
         active = at < total;
@@ -1183,10 +1332,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         if (active) {
             const uint4 *e = W.ent[par] + 4 * (size_t)mine;
             const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
-            q = c0.x; cell = c0.y; endCell = c0.z; excluded = c0.w;
+            q = c0.x; cell = c0.y & 0xffffffu; endCell = c0.z; excluded = c0.w;
             dx = __uint_as_float(c1.x); dy = __uint_as_float(c1.y); dz = __uint_as_float(c1.z); tmin = __uint_as_float(c1.w);
             o = mk(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); tmax = __uint_as_float(c2.w);
             d = mk(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+            seg = c3.w >> 24;
         }
     } else {
         const uint32_t i = threadIdx.x;

@@ -23,6 +23,17 @@ class _Mesh(C.Structure):  # rtHipMesh
                 ("cornerNormals", C.c_void_p), ("cornerUv", C.c_void_p), ("polygonMaterial", C.c_void_p)]
 
 
+class _ObjMaterial(C.Structure):  # rtHipObjMaterial
+    _fields_ = [("name", C.c_char * 64), ("kd", C.c_float * 3), ("ke", C.c_float * 3), ("hasKe", C.c_int32), ("dissolve", C.c_float),
+                ("reflect", C.c_float), ("hasReflect", C.c_int32), ("map", (C.c_char * 256) * 5)]
+
+
+class _ObjData(C.Structure):  # rtHipObjData
+    _fields_ = [("pointCount", C.c_uint32), ("points", C.c_void_p), ("polygonCount", C.c_uint32), ("polygons", C.c_void_p),
+                ("cornerNormals", C.c_void_p), ("cornerUv", C.c_void_p), ("polygonMaterial", C.c_void_p),
+                ("materialCount", C.c_uint32), ("materials", C.POINTER(_ObjMaterial))]
+
+
 class _Channel(C.Structure):  # rtHipChannelSpec
     _fields_ = [("enabled", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("pixels", C.c_void_p)]
 
@@ -50,6 +61,11 @@ def _lib():
         L.rtHipPlanesToRgb8.argtypes = [u32, u32, vp, vp, vp, vp, C.c_int]
         L.rtHipWriteBmp.argtypes = [C.c_char_p, u32, u32, vp, vp, vp, C.c_int]
         L.rtHipWritePpm.argtypes = [C.c_char_p, u32, u32, vp, vp, vp]
+        L.rtHipObjRead.argtypes = [C.c_char_p, C.POINTER(_ObjData)]
+        L.rtHipObjFree.restype = None
+        L.rtHipObjFree.argtypes = [C.POINTER(_ObjData)]
+        L.rtHipImageRead.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(vp)]
+        L.rtHipProjectUv.argtypes = [C.c_int, fp, fp, f32, f32, f32, f32, C.c_int, fp]
         _bound = True
     return L
 
@@ -184,6 +200,75 @@ def scene_from_meshes(meshes: Sequence[Mesh], materials: Sequence[dict], lights:
                  sample_count=samples, vertex=vertex, tri_index=tri_index, tri_material=tri_material, tri_uv=tri_uv, tri_normal=tri_normal,
                  mat_size=mat_size, mat_start=mat_start, textures=textures, light_type=ltype, light_pos=lpos, light_dir=ldir,
                  light_col=lcol, light_radius=lrad, light_half_att=lhalf, name=name)
+
+
+PROJ_SPHERICAL, PROJ_CYLINDRICAL, PROJ_FLAT, PROJ_CUBIC, PROJ_FRONTAL, PROJ_SPATIAL, PROJ_UVW, PROJ_SHRINKWRAP, PROJ_VOLUMESHADER = 0, 1, 2, 3, 4, 5, 6, 7, 10
+
+
+def project_uv(projection: int, point, normal, offset=(0.0, 0.0), length=(1.0, 1.0), tile: bool = True, start=(0.0, 0.0)):
+    """ShdProjectPoint (render.cpp:495-673).  Returns ((u, v) as float32, inside)."""
+    uv = np.asarray(start, np.float32).copy()
+    inside = _lib().rtHipProjectUv(int(projection), _f3(point), _f3(normal), float(offset[0]), float(offset[1]), float(length[0]), float(length[1]),
+                                   1 if tile else 0, uv.ctypes.data_as(C.POINTER(C.c_float)))
+    return uv, bool(inside)
+
+
+def read_image(path: str) -> np.ndarray:
+    """PPM (P6 / P3) or BMP (24 / 32 bit) -> [h,w,3] uint8, top row first."""
+    w, h, px = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    rc = _lib().rtHipImageRead(path.encode(), C.byref(w), C.byref(h), C.byref(px))
+    if rc != 0:
+        raise OSError(f"rtHipImageRead({path}) failed ({rc})")
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    C.memmove(out.ctypes.data, px.value, out.nbytes)
+    R.lib().rtHipFree(px)
+    return np.ascontiguousarray(out[:, :, :3])
+
+
+def read_obj(path: str):
+    """A Wavefront OBJ (+ MTL) as (Mesh, materials): the mesh in rtHipMesh's shape, the materials as the dicts bake_materials takes
+    (render.cpp:1136-1309's channel rules then apply): colour = map_Kd image or Kd; transparency on when d < 1 or map_d is given
+    (1x1 of 1 - d without an image); reflection on when `refl` or map_refl is given; bump from map_bump; luminance from map_Ke or Ke."""
+    d = _ObjData()
+    rc = _lib().rtHipObjRead(path.encode(), C.byref(d))
+    if rc != 0:
+        raise OSError(f"rtHipObjRead({path}) failed ({rc})")
+    try:
+        def arr(ptr, shape, dtype):
+            if not ptr:
+                return None
+            out = np.empty(shape, dtype)
+            C.memmove(out.ctypes.data, ptr, out.nbytes)
+            return out
+        n = d.polygonCount
+        mesh = Mesh(points=arr(d.points, (d.pointCount, 4), np.float32)[:, :3], polygons=arr(d.polygons, (n, 4), np.int32),
+                    corner_normals=None if not d.cornerNormals else arr(d.cornerNormals, (n, 4, 4), np.float32)[:, :, :3],
+                    corner_uv=arr(d.cornerUv, (n, 4, 2), np.float32), polygon_material=arr(d.polygonMaterial, (n,), np.int32))
+        materials = []
+        for i in range(d.materialCount):
+            m = d.materials[i]
+            maps = [bytes(m.map[c]).split(b"\0", 1)[0].decode() for c in range(5)]
+            byte3 = lambda v: np.clip(np.round(np.asarray(v, np.float64) * 255.0), 0, 255).astype(np.uint8).reshape(1, 1, 3)
+            mat = dict(name=m.name.decode(), rgb=tuple(m.kd), brightness=1.0)
+            mat["color"] = read_image(maps[0]) if maps[0] else True
+            if maps[1]:
+                mat["reflection"] = read_image(maps[1])
+            elif m.hasReflect:
+                mat["reflection"] = byte3([m.reflect] * 3)
+            if maps[2]:
+                mat["transparency"] = read_image(maps[2])
+            elif m.dissolve < 1.0:
+                mat["transparency"] = byte3([1.0 - m.dissolve] * 3)
+            if maps[3]:
+                mat["bump"] = read_image(maps[3])
+            if maps[4]:
+                mat["luminance"] = read_image(maps[4])
+            elif m.hasKe:
+                mat["luminance"] = byte3(m.ke)
+            materials.append(mat)
+        return mesh, materials
+    finally:
+        _lib().rtHipObjFree(C.byref(d))
 
 
 def planes_to_rgb8(r, g, b, low_byte_compat: bool = False) -> np.ndarray:

@@ -68,6 +68,7 @@ RESIDENT_SYMBOLS = [
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
     "rtHipDeviceKat", "rtHipTune", "rtHipTestHashBytes",
     "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
+    "rtHipObjRead", "rtHipObjFree", "rtHipImageRead", "rtHipProjectUv",
 ]
 
 _lib = None
@@ -164,7 +165,7 @@ def lib() -> C.CDLL:
 _ENV_KEYS = {
     "RT_HIP_STAGE_MB": "stage_mb", "RT_WF_EXTRA_FACTOR": "extra_factor", "RT_WF_STATE_MB": "state_mb", "RT_WF_GROUPS": "groups",
     "RT_WF_LOOKAHEAD": "lookahead", "RT_WF_FAST_QUOTIENT": "fast_quotient", "RT_WF_SPIN_LIMIT": "spin_limit",
-    "RT_WF_APPEND_RAYS": "append_rays", "RT_WF_SLICE_RAYS": "slice_rays", "RT_WF_SMALL_SLICES": "small_slices", "RT_WF_GROUP_RAYS": "group_rays",
+    "RT_WF_APPEND_RAYS": "append_rays", "RT_WF_ORDERED_FIRST": "ordered_first", "RT_WF_EXTRA_FACTOR": "extra_factor", "RT_WF_SLICE_RAYS": "slice_rays", "RT_WF_SMALL_SLICES": "small_slices", "RT_WF_GROUP_RAYS": "group_rays",
     "RT_WF_BLOCKING": "blocking", "RT_WF_BATCH_PLAN": "batch_plan", "RT_WF_PLAN_ROUNDS": "plan_rounds", "RT_HIP_PIPELINE": "pipeline",
     "RT_HIP_TIMING": "timing", "RT_HIP_VIRTUAL_DEVICES": "virtual_devices", "RT_HIP_CACHE": "cache",
 }

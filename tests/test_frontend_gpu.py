@@ -48,3 +48,31 @@ def test_command_line_harness_writes_the_image(tmp_path, hip_lib):
     F.write_bmp(want_path, *want)
     assert data == open(want_path, "rb").read()
     R.lib().rtHipCacheClear()
+
+
+def test_obj_file_to_image_file_on_the_gpu(tmp_path, hip_lib):
+    """The tool's path for a host without Cinema 4D: tests/data/scene.obj (quads, triangles, a fanned pentagon, an MTL with a PPM
+    colour map, a BMP bump map, a transparent + reflective material and an emissive one) -> front-end arrays -> lists on the device ->
+    RaytraceAll -> BMP, through the command line; the planes must be the oracle's for the same arrays, the file the one the sinks
+    write from the oracle's planes."""
+    from conftest import ROOT
+    from opencl_render_amd import __main__ as cli, scene as S
+    obj = os.path.join(ROOT, "tests", "data", "scene.obj")
+    out = str(tmp_path / "obj.bmp")
+    argv = ["--obj", obj, "--eye", "2.6", "2.2", "-3.4", "--look-at", "0", "0.4", "0", "--fov", "55", "--width", "192", "--height", "128",
+            "--samples", "3", "--out", out]
+    assert cli.main(argv) == 0
+    data = open(out, "rb").read()
+    mesh, materials = F.read_obj(obj)
+    sc = F.scene_from_meshes([mesh], materials, [dict(type=S.LIGHT_DISTANT, dir=(0.3, -0.8, 0.5))], (2.6, 2.2, -3.4), (0, 0.4, 0), (0, 1, 0),
+                             np.radians(55.0), 192, 128, samples=3)
+    assert sc.triangle_count == 6 * 2 + 4 + 3 and sc.material_count == 4
+    R.build_lists(sc)
+    want = O.oracle_render(sc, threads=os.cpu_count() or 1)
+    want_path = str(tmp_path / "oracle.bmp")
+    F.write_bmp(want_path, *want)
+    assert data == open(want_path, "rb").read()
+    rgb = F.read_image(out)                       # the library reads back its own file
+    assert np.array_equal(rgb, F.planes_to_rgb8(*want))
+    assert (rgb.reshape(-1, 3).max(axis=1) > 0).mean() > 0.5 and len(np.unique(rgb[:, :, 0])) > 40  # a picture: floor texture, box, pyramid, sign
+    R.lib().rtHipCacheClear()

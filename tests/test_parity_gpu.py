@@ -252,13 +252,14 @@ def test_full_size_partition_and_primary_only_properties(full_size_scene):
     {"RT_WF_SEG": "16,16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1,1"},   # every ray cut into segments of ~16 cell visits, whatever the round size
     {"RT_WF_SEG": "40,24,12,8,8"},                            # finer still for small rounds
     {"RT_WF_SEG": "4096,4096,4096,4096,4096"},                  # never cut
-    {"RT_WF_APPEND_RAYS": "0"},                            # every round goes through the counting sort
-    {"RT_WF_APPEND_RAYS": "4000000000", "RT_WF_SEG": "24,24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1,1"},  # no round does, all rays cut
+    {"RT_WF_APPEND_RAYS": "0"},                            # every round is an ordered one (planned by the logic kernel, counting sort)
+    {"RT_WF_APPEND_RAYS": "4000000000", "RT_WF_ORDERED_FIRST": "0", "RT_WF_SEG": "24,24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1,1"},  # no round is ordered: the trace kernel plans and cuts every ray
+    {"RT_WF_ORDERED_FIRST": "0", "RT_WF_GROUP_RAYS": "16"},    # ... in workgroups of 16 rays
     {"RT_WF_LOOKAHEAD": "0"},                              # one ray in flight per path
     {"RT_WF_GROUPS": "3"},                                 # three concurrent tile groups per instance
     {"RT_WF_GROUPS": "2", "RT_WF_SEG": "16,16,16,16,16", "RT_WF_SEG_RAYS": "1,1,1,1", "RT_WF_LOOKAHEAD": "0"},
     {"RT_WF_SLICE_RAYS": "0"},                              # every round spreads its entries over all 256 queue slices per kind
-    {"RT_WF_SLICE_RAYS": "4000000000", "RT_WF_SMALL_SLICES": "1", "RT_WF_APPEND_RAYS": "4000000000"},  # one slice per kind from round 1 on, nothing ordered
+    {"RT_WF_SLICE_RAYS": "4000000000", "RT_WF_SMALL_SLICES": "1", "RT_WF_APPEND_RAYS": "4000000000", "RT_WF_ORDERED_FIRST": "0"},  # one slice per kind from round 1 on, nothing ordered
     {"RT_WF_SLICE_RAYS": "20000", "RT_WF_SMALL_SLICES": "4", "RT_WF_APPEND_RAYS": "0", "RT_WF_SEG": "24,24,24,24,24", "RT_WF_SEG_RAYS": "1,1,1,1"},  # slices merge mid-frame, every round ordered and cut
     {"RT_WF_BLOCKING": "1"},                                # every batch of every frame watched
     {"RT_WF_FAST_QUOTIENT": "0"},                          # every wave divides the long way (the default picks per wave: test_kat_gpu.py)
@@ -305,22 +306,38 @@ def test_dropin_all_gpus_mode_threads_and_tile_deal(monkeypatch):
     assert_planes((r, g, b), O.oracle_render(sc, threads=os.cpu_count() or 1), "640x360 soup over 5 instances")
 
 
-@pytest.mark.parametrize("append_rays", ["4000000000", "0"])  # every round appended | every round counting-sorted
-def test_region_b_overflow_keeps_rays_whole(monkeypatch, append_rays):
-    """Every ray of a full-coverage 640x360 frame is cut into segments of ~8 cell visits: the extra segments of the first
-    rounds (several million) do not fit region B of the entry arrays (2 x capacity = 524 288 entries here), so hundreds of
-    waves find it full while others still fit.  A reservation that does not fit must leave its rays whole and must
-    not disturb anybody else's slots (the add is never undone, readers clamp the count, the straddling range is marked
-    empty: wf_logic_kernel)."""
+@pytest.mark.parametrize("planner", ["logic", "trace"])
+def test_every_ray_cut_into_short_segments(monkeypatch, planner):
+    """Every ray of a full-coverage 640x360 frame is cut into segments of ~8 cell visits.
+    planner = logic: every round is an ordered one (the logic kernel plans and cuts); the further segments of the first rounds
+    (several million) do not fit region B of the entry arrays (1 x capacity here), so hundreds of waves find it full while others
+    still fit.  A reservation that does not fit must leave its rays whole and must not disturb anybody else's slots (the add is
+    never undone, readers clamp the count, the straddling range is marked empty: wf_logic_kernel).
+    planner = trace: no round is ordered (the trace kernel's workgroups plan and cut, also the dense first round): a workgroup's
+    128 rays would make far more than its 256 lanes' worth of segments, so every workgroup cuts coarser (wf_trace_kernel<false>)."""
     monkeypatch.setenv("RT_WF_SEG", "8,8,8,8,8")
     monkeypatch.setenv("RT_WF_SEG_RAYS", "1,1,1,1")
-    monkeypatch.setenv("RT_WF_APPEND_RAYS", append_rays)
+    if planner == "logic":
+        monkeypatch.setenv("RT_WF_APPEND_RAYS", "0")
+        monkeypatch.setenv("RT_WF_EXTRA_FACTOR", "1")
+    else:
+        monkeypatch.setenv("RT_WF_APPEND_RAYS", "4000000000")
+        monkeypatch.setenv("RT_WF_ORDERED_FIRST", "0")
+        monkeypatch.setenv("RT_WF_GROUP_RAYS", "128")
     sc = S.make_soup(640, 360, 40_000, 0.06, seed=31, samples=1)
     R.build_lists(sc)
-    got = R.render_resident(sc, 0)
-    assert (got[0] > 0).mean() > 0.85  # nearly every pixel is a path
     want = O.oracle_render(sc, threads=os.cpu_count() or 1)
-    assert_planes(got, want, f"region B overflow, RT_WF_APPEND_RAYS={append_rays}")
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        got = rs.readback()
+        assert (np.asarray(got[0]) > 0).mean() > 0.85  # nearly every pixel is a path
+        assert_planes(got, want, f"every ray cut at 8 visits, planned by the {planner} kernel, watched frame")
+        rs.render()
+        assert not rs.finish()
+        assert_planes(rs.readback(), want, f"every ray cut at 8 visits, planned by the {planner} kernel, planned frame")
+    finally:
+        rs.close()
 
 
 def test_walk_guard_fails_the_frame(monkeypatch):
