@@ -8,7 +8,8 @@ A "step" is one frame: every rank renders its 128x128 tiles of the frame (one la
 scene resident in its HBM), the tile buffers are gathered to rank 0 (RCCL) and rank 0 scatters them into the three
 row-major u16 planes on its device.  Inputs are resident before the timed region; outputs stay on the device for
 `value` / `ms_per_step`; `ms_per_frame_with_d2h` is the same loop with the planes copied to pinned host memory every frame,
-`ms_per_frame_with_d2h_pipelined` the same with frame i's copy on a second stream under frame i+1's kernels.
+`ms_per_frame_with_d2h_pipelined` the same with frame i's copy on a second stream under frame i+1's kernels,
+`ms_per_frame_watched` a frame nothing is known about (every frame of a second scene instance watched: queue read-backs, guessed layouts).
 The same frame is split over more GPUs as N grows => "scaling": "strong".
 
 Workloads (synthetic seeded triangle soups, lists built by the library's host builders):
@@ -254,6 +255,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = rs.kernel_time_ms()
+    # ---- what a frame costs when NOTHING is known about it: every frame watched (the queue read back between round chunks, layouts
+    # guessed), as the first frame of a scene or after a camera move is.  `value` is the steady state of a resident scene; this is the
+    # other end.  A second instance of the scene, built with the library told to watch every frame.
+    ms_watched = None
+    if world == 1:
+        os.environ["RT_WF_BLOCKING"] = "1"
+        try:
+            rw = R.ResidentScene(sc, local_rank, my_tiles)
+        finally:
+            del os.environ["RT_WF_BLOCKING"]
+        for _ in range(2):
+            rw.render(); rw.sync()
+        t3 = time.perf_counter()
+        n_watched = max(3, args.steps // 2)
+        for _ in range(n_watched):
+            rw.render(); rw.sync()
+        ms_watched = 1e3 * (time.perf_counter() - t3) / n_watched
+        rw.close()
 
     # ---- un-timed: per-stage device time (HIP events around every launch), work counters for the byte model
     # (instrumented kernel variant), and one more frame for the parity gate --------------------------------------------
@@ -317,6 +336,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_frame_with_d2h": round(ms_with_d2h, 4),
             "ms_per_frame_with_d2h_pipelined": round(ms_with_d2h_pipelined, 4),
+            "ms_per_frame_watched": None if ms_watched is None else round(ms_watched, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -705,7 +705,9 @@ RtRoundMode mode_for(const Tuning &T, uint32_t round, uint64_t rays, uint32_t sl
     if (m.slices > slicesBefore) m.slices = slicesBefore; // a slice holds at most the paths of its shards: slices only ever merge
     // rays per workgroup of the trace kernel: about 256 lanes / the segments a ray of this round is expected to be cut into ...
     // ... and few enough workgroups for all of them to run at once (5 per CU): the round lasts as long as its slowest workgroup
-    m.groupRays = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(16, ((rays + 1099) / 1100 + 15) / 16 * 16));
+    // (at most 64: with 128 -- two segments per ray on average fill the 256 lanes -- every second workgroup has to cut coarser, and its
+    // longer segments are the round's duration: 4K, 232 k rays, 403 us against 273)
+    m.groupRays = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(16, ((rays + 1099) / 1100 + 15) / 16 * 16));
     if (T.groupRays >= 1u && T.groupRays <= 128u) m.groupRays = T.groupRays;
     return m;
 }

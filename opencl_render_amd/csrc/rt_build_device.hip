@@ -269,7 +269,7 @@ extern "C" int rtHipBuildCameraListDevice(int device, cl_uint W, cl_uint H, cons
 // (cell, triangle) pairs become 64-bit keys cell << 32 | triangle, radix-sorted: the lists come out cell-major with ascending
 // triangles, which is what the reference's sort on cell*T+tri gives (:707).
 #define RT_FILL_LOCAL 48u        // cells a thread's own fill may hold before the triangle is handed to a workgroup
-#define RT_FILL_QUEUE (1u << 22) // cells per workgroup fill
+#define RT_FILL_QUEUE (1u << 24) // cells per workgroup fill: every cell of the grid (a cell enters a fill once), so that a floor across a scene of a few vertices -- whose 256 planes per axis are a handful of distinct values -- cannot overflow it; 4 GB of build scratch of the 288
 #define RT_FILL_GROUPS 64u
 
 namespace {

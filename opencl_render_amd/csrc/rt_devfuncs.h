@@ -34,7 +34,21 @@ enum { ST_SAMPLES = 0, ST_PCAND, ST_GRAYS, ST_GCELLS, ST_GCAND, ST_HITS, ST_TEXE
 struct Counters { uint32_t v[ST_COUNT]; };
 
 // ---- PRNG (raytrace_opencl.c:1-23) ---------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t rol64(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
+// rotl64 (raytrace_opencl.c:1-3) by a compile-time amount: two v_alignbit_b32 -- one per half of the result, each picking 32 bits out of
+// the 64 of (hi:lo) or (lo:hi) -- where the shift-shift-or of the source spelling costs four 64-bit instructions.  The generator
+// makes 16 rotates per draw and the kernels that draw are bound by instruction issue (profiles/r02_primary_4k_valu.json).
+__device__ __forceinline__ uint64_t rol64(uint64_t v, int n)
+{
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (n == 0) return v;
+    if (n == 32) return ((uint64_t)lo << 32) | hi;
+    if (n < 32) { // result.hi = (hi:lo) >> (32 - n), result.lo = (lo:hi) >> (32 - n)
+        const uint32_t rh = __builtin_amdgcn_alignbit(hi, lo, 32 - n), rl = __builtin_amdgcn_alignbit(lo, hi, 32 - n);
+        return ((uint64_t)rh << 32) | rl;
+    }
+    const uint32_t rh = __builtin_amdgcn_alignbit(lo, hi, 64 - n), rl = __builtin_amdgcn_alignbit(hi, lo, 64 - n); // a rotate by n - 32 of the swapped halves
+    return ((uint64_t)rh << 32) | rl;
+}
 __device__ __forceinline__ uint64_t xs64star(uint64_t v)
 {
     v ^= v >> 12;

@@ -663,3 +663,38 @@ def test_more_lights_than_the_logic_kernel_keeps_in_lds():
     sc64 = S.make_soup(96, 64, 1500, 0.2, seed=19, samples=1, lights=lights[:64])
     R.build_lists(sc64)
     assert not np.array_equal(O.oracle_render(sc64, threads=os.cpu_count() or 1)[0], want[0])
+
+
+# ---- the plugin's own operating point -----------------------------------------------------------------------------------------
+# The dialog's defaults are 1024 x 768 at 100 samples per pixel (reference render.cpp:176-182): many sample batches per frame, the
+# per-sample truncated saturating accumulate (raytrace_opencl.c:726-741) at full depth, the further batches of a watched frame issued
+# from the first batch's launch plan.  Sampled rows against the OpenMP oracle (the whole frame is 78 M primary samples).
+
+def test_dialog_defaults_1024x768_100_samples():
+    sc = S.make_soup(1024, 768, 100_000, 0.02, seed=2024, samples=100, name="dialog defaults")
+    R.build_lists(sc)
+    ok, r, g, b = R.raytrace_all(1, sc)      # the first (watched) frame of a scene, as the plugin renders it
+    assert ok, R.last_error()
+    _assert_sampled_rows(sc, (r, g, b), 24, "1024x768, S=100, drop-in")
+    ok, r2, g2, b2 = R.raytrace_all(1, sc)   # the resident scene again: every batch from the plan
+    assert ok and np.array_equal(r, r2) and np.array_equal(g, g2) and np.array_equal(b, b2)
+    assert len(np.unique(r)) > 2000           # 100 samples: a smooth picture, not a few levels
+    R.lib().rtHipCacheClear()
+
+
+def test_1080p_16_samples_in_several_batches(monkeypatch):
+    """1920x1080 at S=16 with a path-state budget that forces four batches of four samples at a real size."""
+    monkeypatch.setenv("RT_WF_STATE_MB", "16000")
+    sc = S.make_soup(1920, 1080, 300_000, 0.008, seed=77, samples=16, name="1080p S=16")
+    R.build_lists(sc)
+    rs = R.ResidentScene(sc, 0)
+    try:
+        rs.render()
+        got = rs.readback()
+        _assert_sampled_rows(sc, got, 40, "1920x1080, S=16, watched frame with planned further batches")
+        rs.render()
+        assert not rs.finish()
+        again = rs.readback()
+        assert all(np.array_equal(a, b) for a, b in zip(got, again))
+    finally:
+        rs.close()
