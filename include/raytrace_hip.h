@@ -186,6 +186,10 @@ const char *rtHipLastError(void);
  * tileCount/tileIds select the 128x128 tiles this scene instance will render (row-major tile ids); NULL/0 = all.
  * Only those tiles' slices of the camera lists are uploaded.  Returns NULL on failure. */
 rtHipScene *rtHipSceneCreate(int device, const rtHipSceneDesc *desc, const cl_uint *tileIds, cl_uint tileCount);
+/* The same for a further instance of a scene that is already resident somewhere (`like`, built from the same description, on this or
+ * another device): geometry, grid, materials and lights are copied from it device to device (hipMemcpyPeerAsync: xGMI between
+ * GPUs) instead of uploaded and reshaped once more; only the instance's own tiles, camera ranges and path state are made anew. */
+rtHipScene *rtHipSceneCreateLike(int device, const rtHipSceneDesc *desc, const cl_uint *tileIds, cl_uint tileCount, const rtHipScene *like);
 void        rtHipSceneDestroy(rtHipScene *scene);
 
 /* Bytes of HBM held by the scene. */
@@ -423,6 +427,11 @@ int rtHipDeviceKat(int device, int op, cl_uint count, const void *in, cl_uint in
  * "slice_rays", "small_slices", "group_rays", "blocking", "batch_plan", "pipeline", "timing", "cache", and the test hooks "plan_rounds",
  * "plan_grid_tiny", "virtual_devices".  Returns 0, -1 for an unknown key. */
 int rtHipTune(const char *key, double value);
+
+/* TEST-ONLY: device addresses held by the first scene of RaytraceAll's cache -- triangle records, shading rows, the grid's pair
+ * records, material descriptors, texture atlas, camera list -- so that a test can see which parts a call left in place.
+ * Returns 0, -2 when nothing is cached. */
+int rtHipTestCachePointers(const void *out[6]);
 
 /* TEST-ONLY: the content hash RaytraceAll's scene cache compares per input array (rt_api.cpp, hash_chunk), on the host.  Two byte
  * strings that differ must hash differently for the cache to notice an edit; tests/test_abi.py probes the tail handling. */

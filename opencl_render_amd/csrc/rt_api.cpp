@@ -185,6 +185,7 @@ struct rtHipScene {
     // Device allocations by PART (tiles + outputs | camera lists | geometry | grid | materials | lights | path state): the drop-in
     // layer's cache replaces the parts whose inputs changed between two RaytraceAll calls and keeps the others in HBM.
     std::vector<void *> partAllocs[PART_COUNT];
+    std::vector<uint64_t> partSizes[PART_COUNT]; // bytes of every allocation (a peer instance copies the shared parts device to device)
     uint64_t partBytes[PART_COUNT] = { 0 };
     int curPart = PART_FIXED;
     Stager stager;
@@ -245,6 +246,7 @@ struct rtHipScene {
         const uint64_t n = count ? count : 1;
         HIP_OK(hipMalloc(&p, n * sizeof(T)));
         partAllocs[curPart].push_back(p);
+        partSizes[curPart].push_back(n * sizeof(T));
         partBytes[curPart] += n * sizeof(T);
         bytes += n * sizeof(T);
         if (count) {
@@ -260,6 +262,7 @@ struct rtHipScene {
         const uint64_t n = count ? count : 1;
         HIP_OK(hipMalloc(&p, n * sizeof(T)));
         partAllocs[curPart].push_back(p);
+        partSizes[curPart].push_back(n * sizeof(T));
         partBytes[curPart] += n * sizeof(T);
         bytes += n * sizeof(T);
         *dst = (T *)p;
@@ -271,6 +274,7 @@ struct rtHipScene {
         if (stream) (void)hipStreamSynchronize(stream);
         for (void *p : partAllocs[part]) (void)hipFree(p);
         partAllocs[part].clear();
+        partSizes[part].clear();
         bytes -= partBytes[part];
         partBytes[part] = 0;
     }
@@ -646,7 +650,45 @@ void refresh_views(rtHipScene *sc)
     }
 }
 
-int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds, cl_uint tileCount)
+// One of the parts every instance of a scene holds alike (geometry, grid, materials, lights), copied from an instance that has it --
+// device to device, over xGMI between GPUs -- instead of uploaded and reshaped once more: the "all GPUs" mode builds the scene once
+// ("upload once via root then broadcast").  The source's work on the part must be complete (its builders synchronise).
+int clone_part(rtHipScene *dst, const rtHipScene *src, int part)
+{
+    dst->release_part(part);
+    dst->curPart = part;
+    std::vector<std::pair<const char *, char *>> moved; // (source block, copy)
+    for (size_t i = 0; i < src->partAllocs[part].size(); ++i) {
+        char *p = nullptr;
+        const uint64_t n = src->partSizes[part][i];
+        if (dst->alloc<char>(n, &p)) return -1;
+        HIP_OK(hipMemcpyPeerAsync(p, dst->device, src->partAllocs[part][i], src->device, n, dst->stream));
+        moved.emplace_back((const char *)src->partAllocs[part][i], p);
+    }
+    auto at = [&](const void *old) -> const void * { // the copy of the block `old` points to (the builders hand out block starts only)
+        for (auto &m : moved) if (m.first == (const char *)old) return m.second;
+        return nullptr;
+    };
+    const RtDevScene &S = src->dev;
+    RtDevScene &D = dst->dev;
+#define RT_MOVE(field) D.field = (decltype(D.field))at(S.field)
+    if (part == PART_GEOMETRY) { D.triangleCount = S.triangleCount; RT_MOVE(triRec); RT_MOVE(triShade); }
+    if (part == PART_GRID) {
+        D.planesTame = S.planesTame; D.cellCount = S.cellCount;
+        RT_MOVE(boxMin); RT_MOVE(cellLut); RT_MOVE(gridStart); RT_MOVE(gridList); RT_MOVE(gridBits); RT_MOVE(gridBlockSparse); RT_MOVE(pairRec);
+    }
+    if (part == PART_MATERIALS) { D.materialCount = S.materialCount; D.texelCount = S.texelCount; RT_MOVE(matSize); RT_MOVE(matStart); RT_MOVE(textures); RT_MOVE(matRec); }
+    if (part == PART_LIGHTS) {
+        D.lightCount = S.lightCount;
+        RT_MOVE(lightType); RT_MOVE(lightPos); RT_MOVE(lightDir); RT_MOVE(lightCol); RT_MOVE(lightRadius); RT_MOVE(lightHalfAtt); RT_MOVE(lightSpread);
+    }
+#undef RT_MOVE
+    HIP_OK(hipStreamSynchronize(dst->stream));
+    return 0;
+}
+
+// `like`: an instance of the same scene (same inputs) on this or another device whose shared parts are copied instead of built
+int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds, cl_uint tileCount, const rtHipScene *like = nullptr)
 {
     if (!d) return fail("null scene description");
     if (d->width == 0 || d->height == 0) return fail("empty image %ux%u", d->width, d->height);
@@ -670,15 +712,23 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
     };
     if (build_fixed(sc, d, tileIds, tileCount) != 0) return -1;
     mark("tiles, outputs, bump tables");
-    if (build_geometry(sc, d) != 0) return -1;
-    mark("geometry");
-    if (build_grid(sc, d) != 0) return -1;
-    mark("grid + dense view");
-    if (build_camera(sc, d) != 0) return -1;
-    mark("camera lists");
-    if (build_materials(sc, d) != 0) return -1;
-    if (build_lights(sc, d) != 0) return -1;
-    mark("materials + lights");
+    if (like) {
+        for (int part : { PART_GEOMETRY, PART_GRID, PART_MATERIALS, PART_LIGHTS })
+            if (clone_part(sc, like, part) != 0) return -1;
+        mark("geometry, grid, materials, lights (copied from another instance)");
+        if (build_camera(sc, d) != 0) return -1;
+        mark("camera lists");
+    } else {
+        if (build_geometry(sc, d) != 0) return -1;
+        mark("geometry");
+        if (build_grid(sc, d) != 0) return -1;
+        mark("grid + dense view");
+        if (build_camera(sc, d) != 0) return -1;
+        mark("camera lists");
+        if (build_materials(sc, d) != 0) return -1;
+        if (build_lights(sc, d) != 0) return -1;
+        mark("materials + lights");
+    }
     // what only a kernel can tell about the inputs (ids inside the lists): one look at the error word
     HIP_OK(rtp_validate(sc->dev.triangleCount, 0, 0, nullptr, nullptr, sc->camListSize, sc->dev.camList, nullptr, 0, nullptr, sc->prepErr, sc->stream));
     HIP_OK(hipStreamSynchronize(sc->stream));
@@ -955,13 +1005,18 @@ const char *rtHipLastError(void) { return g_error.c_str(); }
 
 rtHipScene *rtHipSceneCreate(int device, const rtHipSceneDesc *desc, const cl_uint *tileIds, cl_uint tileCount)
 {
+    return rtHipSceneCreateLike(device, desc, tileIds, tileCount, nullptr);
+}
+
+rtHipScene *rtHipSceneCreateLike(int device, const rtHipSceneDesc *desc, const cl_uint *tileIds, cl_uint tileCount, const rtHipScene *like)
+{
     g_error.clear();
     const int n = rtHipDeviceCount();
     if (n <= 0) { fail("no HIP device available: libraytrace_hip has no CPU fallback"); return nullptr; }
     if (device < 0 || device >= n) { fail("device %d out of range (%d HIP devices)", device, n); return nullptr; }
     rtHipScene *sc = new rtHipScene();
     sc->device = device;
-    if (scene_build(sc, desc, tileIds, tileCount) != 0) {
+    if (scene_build(sc, desc, tileIds, tileCount, like) != 0) {
         std::string keep = g_error;
         rtHipSceneDestroy(sc);
         g_error = keep;
@@ -1315,6 +1370,7 @@ struct SceneCache {
     std::vector<rtHipScene *> scenes;
     std::vector<std::vector<cl_uint>> tiles; // per scene: its tile ids (empty = all)
     int first = 0, count = 0, devices = 0;
+    Tuning tune;               // the tuning values the scenes were built with: other values, other scenes
     uint32_t width = 0, height = 0, sampleCount = 0;
     uint64_t hash[5] = { 0 };
     bool valid = false;
@@ -1364,6 +1420,16 @@ int rtHipTune(const char *key, double value)
     for (auto &e : table)
         if (k == e.name) { *e.field = u; return 0; }
     return fail("rtHipTune: unknown key '%s'", key);
+}
+
+int rtHipTestCachePointers(const void *out[6])
+{
+    if (!out) return -1;
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    if (!g_cache.valid || g_cache.scenes.empty() || !g_cache.scenes[0]) return -2;
+    const RtDevScene &D = g_cache.scenes[0]->dev;
+    out[0] = D.triRec; out[1] = D.triShade; out[2] = D.pairRec; out[3] = D.matRec; out[4] = D.textures; out[5] = D.camList;
+    return 0;
 }
 
 uint64_t rtHipTestHashBytes(const void *bytes, uint64_t count) { return hash_chunk((const unsigned char *)bytes, (size_t)count); }
@@ -1468,15 +1534,21 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     std::lock_guard<std::mutex> lock(g_cacheMutex);
     SceneCache &C = g_cache;
     const bool useCache = tune.cache != 0;
-    const bool sameSet = C.valid && C.first == first && C.count == count && C.devices == n && C.width == d.width && C.height == d.height &&
-                         (int)C.scenes.size() == count;
-    const bool reuse = useCache && sameSet && C.hash[0] == h[0] && C.hash[1] == h[1] && C.hash[2] == h[2];
-    const bool lightsChanged = !reuse || C.hash[3] != h[3];
-    const bool cameraChanged = !reuse || C.hash[4] != h[4];
-    const bool samplesChanged = !reuse || C.sampleCount != d.sampleCount;
-    if (!reuse) {
+    const bool sameSet = useCache && C.valid && C.first == first && C.count == count && C.devices == n && C.width == d.width && C.height == d.height &&
+                         (int)C.scenes.size() == count && memcmp(&C.tune, &tune, sizeof tune) == 0;
+    // What is rebuilt.  Geometry (triangle records), grid (its dense view holds copies of triangle records: it follows the geometry),
+    // materials, lights, camera lists and the path-state buffers are separate parts of a resident scene, each behind its own gate: a
+    // changed texel re-bakes the materials and leaves the 260 MB of geometry and grid of a 1 M-triangle scene where they are.
+    const bool geometryChanged = !sameSet || C.hash[0] != h[0];
+    const bool gridChanged = geometryChanged || C.hash[1] != h[1];
+    const bool materialsChanged = !sameSet || C.hash[2] != h[2];
+    const bool lightsChanged = !sameSet || C.hash[3] != h[3];
+    const bool cameraChanged = !sameSet || C.hash[4] != h[4];
+    const bool samplesChanged = !sameSet || C.sampleCount != d.sampleCount;
+    const bool reuse = sameSet;
+    if (!sameSet) {
         C.clear();
-        C.first = first; C.count = count; C.devices = n; C.width = d.width; C.height = d.height;
+        C.first = first; C.count = count; C.devices = n; C.width = d.width; C.height = d.height; C.tune = tune;
         C.scenes.assign((size_t)count, nullptr);
         C.tiles.assign((size_t)count, std::vector<cl_uint>());
         if (count > 1)
@@ -1485,27 +1557,37 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
     }
     std::vector<std::string> errors((size_t)count);
     std::vector<char> failed((size_t)count, 0);
-    auto work = [&](int g) { // build or update one device's scene, render its share; errors are thread-local, so they are carried out by hand
-        if (count > 1 && C.tiles[g].empty()) return; // more instances than tiles
+    // build or update one device's scene; errors are thread-local, so they are carried out by hand.  Instance 0 goes first: the others
+    // copy the parts all instances hold alike from it, device to device (clone_part), instead of uploading and reshaping them again
+    auto build = [&](int g) -> bool {
+        if (count > 1 && C.tiles[g].empty()) return true; // more instances than tiles
         bool ok = true;
+        const rtHipScene *root = g > 0 ? C.scenes[0] : nullptr;
         if (!C.scenes[g]) {
-            C.scenes[g] = rtHipSceneCreate((first + g) % n, &d, C.tiles[g].empty() ? nullptr : C.tiles[g].data(), (cl_uint)C.tiles[g].size());
+            C.scenes[g] = rtHipSceneCreateLike((first + g) % n, &d, C.tiles[g].empty() ? nullptr : C.tiles[g].data(), (cl_uint)C.tiles[g].size(), root);
             ok = C.scenes[g] != nullptr;
         } else {
             rtHipScene *sc = C.scenes[g];
             ok = hipSetDevice(sc->device) == hipSuccess;
-            if (ok && lightsChanged) ok = build_lights(sc, &d) == 0;
-            if (ok && cameraChanged) {
-                ok = build_camera(sc, &d) == 0;
-                if (ok) { // ids inside the new list: one look at the validation word
-                    ok = rtp_validate(sc->dev.triangleCount, 0, 0, nullptr, nullptr, sc->camListSize, sc->dev.camList, nullptr, 0, nullptr, sc->prepErr, sc->stream) == hipSuccess &&
-                         hipStreamSynchronize(sc->stream) == hipSuccess && sc->check_prep() == 0;
-                }
-            }
+            if (ok && geometryChanged) ok = (root ? clone_part(sc, root, PART_GEOMETRY) : build_geometry(sc, &d)) == 0;
+            if (ok && gridChanged) ok = (root ? clone_part(sc, root, PART_GRID) : build_grid(sc, &d)) == 0;
+            if (ok && materialsChanged) ok = (root ? clone_part(sc, root, PART_MATERIALS) : build_materials(sc, &d)) == 0;
+            if (ok && lightsChanged) ok = (root ? clone_part(sc, root, PART_LIGHTS) : build_lights(sc, &d)) == 0;
+            if (ok && cameraChanged) ok = build_camera(sc, &d) == 0;
+            if (ok && (cameraChanged || geometryChanged)) // ids inside the list against the triangles there are now: one look at the validation word
+                ok = rtp_validate(sc->dev.triangleCount, 0, 0, nullptr, nullptr, sc->camListSize, sc->dev.camList, nullptr, 0, nullptr, sc->prepErr, sc->stream) == hipSuccess &&
+                     hipStreamSynchronize(sc->stream) == hipSuccess && sc->check_prep() == 0;
             if (ok && (samplesChanged || (sc->dev.lightCount > 1) != sc->wfMultiLight)) ok = build_wavefront(sc, d.sampleCount) == 0;
-            if (ok && (lightsChanged || cameraChanged)) sc->planRounds = 0; // other rays: the next frame watches its queue again
+            if (ok && (lightsChanged || cameraChanged || gridChanged || materialsChanged)) sc->planRounds = 0; // other rays: the next frame watches its queue again
             if (ok) refresh_views(sc);
         }
+        if (!ok) { failed[g] = 1; errors[g] = g_error; }
+        return ok;
+    };
+    auto work = [&](int g, bool built) { // (instance 0 is built before the threads start), then render the instance's share
+        if (count > 1 && C.tiles[g].empty()) return;
+        bool ok = built || build(g);
+        if (failed[g]) return;
         if (ok) {
             rtHipScene *sc = C.scenes[g];
             sc->progress = &g_progress;
@@ -1529,10 +1611,11 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
         }
         if (!ok) { failed[g] = 1; errors[g] = g_error; }
     };
-    if (count == 1) work(0);
-    else {
+    const bool rootBuilt = build(0);
+    if (count == 1) { if (rootBuilt) work(0, true); }
+    else if (rootBuilt) {
         std::vector<std::thread> pool;
-        for (int g = 0; g < count; ++g) pool.emplace_back(work, g);
+        for (int g = 0; g < count; ++g) pool.emplace_back(work, g, g == 0);
         for (auto &t : pool) t.join();
     }
     bool ok = true;
@@ -1596,7 +1679,7 @@ cl_bool RaytraceAll(cl_uint computationType, cl_uint2 cameraImageDimension, cl_f
         const auto tEnd = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "libraytrace_hip: RaytraceAll: %s; hashing %.1f ms, build/update + render %.1f ms, gather + copy out %.1f ms\n",
-                reuse ? (cameraChanged || lightsChanged || samplesChanged ? "scene reused, parts rebuilt" : "scene reused as it is") : "scene built",
+                reuse ? (cameraChanged || lightsChanged || samplesChanged || gridChanged || materialsChanged ? "scene reused, parts rebuilt" : "scene reused as it is") : "scene built",
                 ms(tCall, tHash), ms(tHash, tRender), ms(tRender, tEnd));
     }
     if (!ok || !useCache) {

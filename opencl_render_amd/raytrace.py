@@ -62,11 +62,11 @@ DROPIN_SYMBOLS = [
     "dot", "cross", "normalize", "vector", "bindf", "GetPointToLineSqLen", "RayIntersectsTriangle", "GetBoxAddress",
 ]
 RESIDENT_SYMBOLS = [
-    "rtHipCacheClear", "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
+    "rtHipCacheClear", "rtHipDeviceCount", "rtHipLastError", "rtHipSceneCreate", "rtHipSceneCreateLike", "rtHipSceneDestroy", "rtHipSceneBytes", "rtHipRenderTiles", "rtHipFrameFinish",
     "rtHipSetPipeline", "rtHipStageTiming", "rtHipStageTimes", "rtHipDebugCounters",
     "rtHipRenderTilesCounted", "rtHipTileBuffer", "rtHipTileBufferBytes", "rtHipDetile", "rtHipDetileStore", "rtHipDeviceAlloc", "rtHipDeviceFree", "rtHipDeviceCopy", "rtHipReadback", "rtHipSync",
     "rtHipKernelTime", "rtHipBuildCameraList", "rtHipBuildCameraListDevice", "rtHipBuildSceneGrid", "rtHipBuildSceneGridDevice", "rtHipFree",
-    "rtHipDeviceKat", "rtHipTune", "rtHipTestHashBytes",
+    "rtHipDeviceKat", "rtHipTune", "rtHipTestCachePointers", "rtHipTestHashBytes",
     "rtHipSetCamera", "rtHipMeshCount", "rtHipMeshFill", "rtHipLightFill", "rtHipBakeMaterials", "rtHipPlanesToRgb8", "rtHipWriteBmp", "rtHipWritePpm",
     "rtHipObjRead", "rtHipObjFree", "rtHipImageRead", "rtHipProjectUv",
 ]
@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
     L.rtHipLastError.restype = C.c_char_p
     L.rtHipSceneCreate.restype = vp
     L.rtHipSceneCreate.argtypes = [C.c_int, C.POINTER(SceneDesc), vp, u32]
+    L.rtHipSceneCreateLike.restype = vp
+    L.rtHipSceneCreateLike.argtypes = [C.c_int, C.POINTER(SceneDesc), vp, u32, vp]
     L.rtHipSceneDestroy.argtypes = [vp]
     L.rtHipSceneDestroy.restype = None
     L.rtHipSceneBytes.restype = u64
@@ -356,14 +358,16 @@ def tiles_of_rank(width: int, height: int, rank: int, world: int) -> np.ndarray:
 class ResidentScene:
     """A scene resident in one GPU's HBM (rtHipScene)."""
 
-    def __init__(self, sc: Scene, device: int = 0, tiles: Optional[Sequence[int]] = None):
+    def __init__(self, sc: Scene, device: int = 0, tiles: Optional[Sequence[int]] = None, like: "Optional[ResidentScene]" = None):
+        """`like`: a resident instance of the same scene whose geometry, grid, materials and lights are copied device to device."""
         L = lib()
         apply_env_tuning()
         self.scene = sc
         self.device = device
         self.tiles = None if tiles is None else np.ascontiguousarray(tiles, np.uint32)
         d = scene_desc(sc)
-        self.handle = L.rtHipSceneCreate(device, C.byref(d), _ptr(self.tiles), 0 if self.tiles is None else len(self.tiles))
+        self.handle = L.rtHipSceneCreateLike(device, C.byref(d), _ptr(self.tiles), 0 if self.tiles is None else len(self.tiles),
+                                             None if like is None else like.handle)
         if not self.handle:
             raise RuntimeError("rtHipSceneCreate failed: " + last_error())
         if self.tiles is None:

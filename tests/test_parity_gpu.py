@@ -698,3 +698,71 @@ def test_1080p_16_samples_in_several_batches(monkeypatch):
         assert all(np.array_equal(a, b) for a, b in zip(got, again))
     finally:
         rs.close()
+
+
+def test_dropin_cache_keeps_the_parts_an_edit_does_not_touch():
+    """SURVEY 8f row 2 to the letter: geometry, grid, materials, lights and camera lists are separate parts of RaytraceAll's
+    resident scene.  A changed texel re-bakes the materials and leaves triangle records, shading rows and the grid's pair records
+    where they are (same device addresses, no free + upload); a moved light touches neither; every picture is the oracle's."""
+    import copy
+    import ctypes as C
+    threads = os.cpu_count() or 1
+    L = R.lib()
+    mats = [dict(color=np.random.default_rng(4).integers(0, 256, (16, 16, 3)), reflection=(0, 0, 0), transparency=(0, 0, 0), bump=(0, 0, 0), luminance=(0, 0, 0))]
+    base = S.make_soup(256, 192, 9000, 0.05, seed=71, samples=2, materials=mats, random_uv=True)
+    R.build_lists(base)
+
+    def check(sc, what):
+        ok, r, g, b = R.raytrace_all(1, sc)
+        assert ok, R.last_error()
+        assert_planes((r, g, b), O.oracle_render(sc, threads=threads), what)
+        ptr = (C.c_void_p * 6)()
+        assert L.rtHipTestCachePointers(ptr) == 0
+        return r, [p for p in ptr]
+
+    first, p0 = check(base, "first call")
+    texel = copy.copy(base)
+    texel.textures = base.textures.copy()
+    texel.textures[:, :3] = 255 - texel.textures[:, :3]
+    pic, p1 = check(texel, "texture atlas changed")
+    assert not np.array_equal(pic, first)
+    assert p1[0] == p0[0] and p1[1] == p0[1] and p1[2] == p0[2], "geometry / grid were rebuilt for a texel edit"
+    light = copy.copy(texel)
+    light.light_dir = texel.light_dir.copy()
+    light.light_dir[0, :3] = (-0.4, -0.7, 0.3)
+    pic2, p2 = check(light, "light moved")
+    assert not np.array_equal(pic2, pic) and p2[:5] == p1[:5], "a moved light rebuilt geometry, grid or materials"
+    grid = copy.copy(light)                       # same triangles, another grid (here: the lists of a coarser neighbour scene are not
+    grid.vertex = light.vertex.copy()             # available, so the geometry moves too: everything but the materials is rebuilt)
+    grid.vertex[:300, 1] += np.float32(0.1)
+    R.build_lists(grid)
+    pic3, p3 = check(grid, "vertices moved")
+    assert p3[3] == p2[3] and p3[4] == p2[4], "materials were rebuilt for a geometry edit"
+    check(base, "back to the first scene")
+    L.rtHipCacheClear()
+
+
+def test_all_gpus_mode_builds_the_scene_once(monkeypatch):
+    """RaytraceAll's all-GPUs id builds the scene on the first instance and copies geometry, grid, materials and lights to the others
+    device to device ('upload once via root then broadcast'); on a one-GPU box the instances share the device
+    (virtual_devices).  Four instances of the 1 M-triangle scene: sampled rows against the oracle, and a first call that costs
+    little more than one instance's (it used to upload and reshape the scene once per instance)."""
+    import time
+    n = R.lib().rtHipDeviceCount()
+    sc = _bench_scene("lambert_1m")
+    R.lib().rtHipCacheClear()
+    t0 = time.perf_counter()
+    ok, r1, g1, b1 = R.raytrace_all(1, sc)
+    one = time.perf_counter() - t0
+    assert ok, R.last_error()
+    R.lib().rtHipCacheClear()
+    monkeypatch.setenv("RT_HIP_VIRTUAL_DEVICES", "4")
+    t0 = time.perf_counter()
+    ok, r, g, b = R.raytrace_all(n + 1, sc)
+    four = time.perf_counter() - t0
+    assert ok, R.last_error()
+    assert np.array_equal(r, r1) and np.array_equal(g, g1) and np.array_equal(b, b1)
+    _assert_sampled_rows(sc, (r, g, b), 16, "1920x1080 / 1 M over 4 instances")
+    print(f"first RaytraceAll on the 1 M-triangle scene: one instance {1e3 * one:.1f} ms, four instances {1e3 * four:.1f} ms wall")
+    assert four < 2.0 * one + 0.05, (one, four)
+    R.lib().rtHipCacheClear()
