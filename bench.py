@@ -317,15 +317,16 @@ def main():
         # only reported when that profile is of this very workload and N=1
         # `traffic` is NOT measured by this run (counters need rocprofv3): it is the fabric (L2-miss) bytes of the dominant kernel
         # per frame from the counter passes committed under profiles/ -- TCC_EA0_RDREQ x 128 B, every request of this kernel is
-        # a 128-byte one (profiles/r02_*) -- and is tagged with the file and the commit it was taken at.  Only given when that
+        # a 128-byte one (profiles/r03_*) -- and is tagged with the file and the commit it was taken at.  Only given when that
         # profile is of this very workload, S=1, N=1.
         traffic = traffic_source = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_trace_fabric_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r03_trace_fabric_traffic.json")))
             key = dom_name.split(" ")[0]
-            if world == 1 and pipeline and prof.get("workload") == args.workload and args.samples == 1 and key in prof["per_frame"]:
-                traffic = int(prof["per_frame"][key]["fabric_read_bytes"] + prof["per_frame"][key].get("write_bytes", 0))
-                traffic_source = f"profiles/r02_trace_fabric_traffic.json @ {prof.get('commit', '?')} (not measured by this run)"
+            rows = [v for k, v in prof["per_frame"].items() if k.split("<")[0] == key]  # (both instantiations of the trace kernel)
+            if world == 1 and pipeline and prof.get("workload") == args.workload and args.samples == 1 and rows:
+                traffic = int(sum(r["fabric_read_bytes"] + r.get("write_bytes", 0) for r in rows))
+                traffic_source = f"profiles/r03_trace_fabric_traffic.json @ {prof.get('commit', '?')} (not measured by this run)"
         except (OSError, ValueError, KeyError):
             traffic = traffic_source = None
         out = {

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
     // an ordered round's classes, per wave: entries of this wave per walk-length class, then where the class's ranks of this wave start
     __shared__ uint32_t waveHist[ORDERED ? 4 : 1][RT_WF_SORT_BINS], waveBase[ORDERED ? 4 : 1][RT_WF_SORT_BINS];
     __shared__ uint8_t cellLut[ORDERED ? 3 * 256 : 4];
-    __shared__ uint8_t itemOwner[ORDERED ? 4 : 1][64 * (RT_WF_MAXSEG - 1)]; // per wave: which lane's ray the i-th further segment belongs to
+    // per wave: whose ray the i-th further segment belongs to, and its rank in the wave | class << 24
+    __shared__ uint8_t itemOwner[ORDERED ? 4 : 1][2 * 64 * (RT_WF_MAXSEG - 1)];
+    __shared__ uint32_t itemWord[ORDERED ? 4 : 1][ORDERED ? 2 * 64 * (RT_WF_MAXSEG - 1) : 1];
     __shared__ float lutScale[3];
     static_assert(RT_WF_SORT_BINS == 64, "one class per lane");
     sh.unit255[threadIdx.x] = (float)threadIdx.x / 255.f;
@@ -882,183 +884,223 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
         // The rays of the next round go to their queue slots now.  An ORDERED round (most lanes have one): as complete trace entries --
         // DDA start state, segments, walk-length class -- so that nothing stands between this kernel and the walk but the placing of
         // the classes.  Any other round: the ray alone; wf_trace_kernel<false> plans and cuts it (stage "trace entries").
-        uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0; // ordered round: segment 0's class and its rank inside this wave
-        uint32_t itemsM = 0, itemsL = 0, itemsAtM = 0, itemsAtL = 0; // further segments of this wave's main / look-ahead rays: how many, and where in region B
-        uint32_t cellM = 0;
         const uint32_t copy = waveId % RT_WF_SORT_COPIES;
-        // walk-length class of an entry that will make v cell visits if it hits nothing (scheduling only).  Two scales: segments of a
-        // finely cut round differ by a few visits, uncut rays by hundreds; class 0 = longest
-        auto visit_class = [](uint32_t v) -> uint32_t {
-            if ((int)v < 1) v = 1;
-            if (v > 767u) v = 767u;
-            return (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
-        };
+        if (!ORDERED) {
 #pragma unroll 1
-        for (int which = 0; which < 2; ++which) {
-            const bool has = which ? emitLa : emit;
-            if (__ballot(has) == 0ull) continue; // wave-uniform
-            const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
-            const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
-            const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
-            uint4 *e = W.ent[outq] + 4 * (size_t)mine;
-            if (has) {
+            for (int which = 0; which < 2; ++which) {
+                const bool has = which ? emitLa : emit;
+                if (!has) continue;
+                const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
+                const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
+                const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
+                uint4 *e = W.ent[outq] + 4 * (size_t)mine;
                 W.pathOf[outq][mine] = a;
                 W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
                 if (which) W.laSlot[a] = mine;
+                reinterpret_cast<uint32_t *>(e)[3] = excluded;
+                reinterpret_cast<uint32_t *>(e)[7] = __float_as_uint(tmin);
                 e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+                e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
             }
-            if (!ORDERED) {
-                if (has) {
-                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
-                    reinterpret_cast<uint32_t *>(e)[7] = __float_as_uint(tmin);
-                    e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u);
-                }
-                continue;
-            }
-            EntryPlan plan;
-            plan.visits = 1; plan.endCell = 0xffffffffu; plan.te = RT_INF;
-            plan.start.cell = 0; plan.start.dx = 0.f; plan.start.dy = 0.f; plan.start.dz = 0.f;
-            uint32_t nseg = 0;
-            if (has) {
+        } else {
+            // walk-length class of an entry that will make v cell visits if it hits nothing (scheduling only).  Two scales: segments of a
+            // finely cut round differ by a few visits, uncut rays by hundreds; class 0 = longest
+            auto visit_class = [](uint32_t v) -> uint32_t {
+                if ((int)v < 1) v = 1;
+                if (v > 767u) v = 767u;
+                return (v < 128u) ? 63u - (v >> 2) : 31u - (v - 128u) / 20u;
+            };
+            // Everything that can be known without touching memory comes first -- both rays' plans, their segments, every entry's class and
+            // its rank inside the wave -- so that the one returned atomic every wave needs (where its classes' ranks start) goes out BEFORE
+            // the entries' stores: a returned atomic waits for every store issued ahead of it, and behind 128 bytes of entry per lane the
+            // wave sat out its own stores' round trip to HBM.  Nothing is read back either: a further segment's class and rank wait in LDS
+            // for the lane that makes its entry.
+            EntryPlan planM, planL;
+            planM.visits = planL.visits = 1; planM.endCell = planL.endCell = 0xffffffffu; planM.te = planL.te = RT_INF;
+            planM.start.cell = planL.start.cell = 0; planM.start.dx = planM.start.dy = planM.start.dz = 0.f; planL.start.dx = planL.start.dy = planL.start.dz = 0.f;
+            uint32_t nsegM = 0, nsegL = 0;
+            // (a round that is cut needs the exact far cell: the cut positions follow from the visit count)
+            const uint8_t *lut = next.segLen >= 4096u ? cellLut : nullptr;
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) { // (one copy of the planning code: two made the kernel a sixth longer)
+                const bool has = which ? emitLa : emit;
+                if (__ballot(has) == 0ull) continue; // wave-uniform
+                const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
+                const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
                 // (a hit's look-ahead ray starts where its shadow ray starts: one plane search for the two -- when the start is the origin
                 // itself, tmin = 0, and lies inside the grid's box, so that BindInCube (:265-322) moves it for neither direction)
                 const bool sameStart = which && emit && lo3.x == ro.x && lo3.y == ro.y && lo3.z == ro.z && latmin == 0.f && rtmin == 0.f &&
                                        planes[0] <= o.x && o.x <= planes[RT_GRID_DIV] && planes[RT_GRID_DIV + 1] <= o.y && o.y <= planes[2 * RT_GRID_DIV + 1] &&
                                        planes[2 * (RT_GRID_DIV + 1)] <= o.z && o.z <= planes[3 * RT_GRID_DIV + 2];
-                // (a round that is cut needs the exact far cell: the cut positions follow from the visit count)
-                plan = plan_ray(planes, o, d, tmin, tmax, sameStart, cellM, next.segLen >= 4096u ? cellLut : nullptr, lutScale);
-                if (!which) cellM = plan.start.cell;
-                nseg = segments_of(plan, d, tmax, next.segLen);
+                if (has) {
+                    const EntryPlan plan = plan_ray(planes, o, d, tmin, tmax, sameStart, planM.start.cell, lut, lutScale);
+                    const uint32_t n = segments_of(plan, d, tmax, next.segLen);
+                    if (which) { planL = plan; nsegL = n; } else { planM = plan; nsegM = n; }
+                }
             }
-            uint32_t extraAt = 0, items = 0, before = 0;
-            // Room in region B for the further segments of this wave's rays: one atomic per wave that cuts anything.  A reservation is
-            // never undone (an add followed by a subtract is not atomic across waves: a later, smaller reservation could land inside
-            // the range the subtract gives back).  A count past extraCap just means "region B is full"; every reader clamps it.  The
-            // one wave whose range straddles the end owns [at, extraCap) and marks those slots empty; waves after it start past the
-            // end and own nothing.  No room, no cutting: the wave's rays stay whole.
-            if (__ballot(nseg > 1u) != 0ull) { // wave-uniform
-                const uint32_t extraMine = nseg > 1u ? nseg - 1u : 0u;
-                uint32_t incl = extraMine;
+            // items = further segments of this wave's rays: those of the main rays first (lane L's start at beforeM), then those of the
+            // look-ahead rays (at itemsM + beforeL)
+            const uint32_t extraM = nsegM > 1u ? nsegM - 1u : 0u, extraL = nsegL > 1u ? nsegL - 1u : 0u;
+            uint32_t itemsM = 0, itemsL = 0, beforeM = 0, beforeL = 0;
+            const bool cutting = __ballot((extraM | extraL) != 0u) != 0ull; // wave-uniform
+            if (cutting) {
+                uint32_t inclM = extraM, inclL = extraL;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t up = __shfl_up(incl, off, 64);
-                    if ((int)lane >= off) incl += up;
+                    const uint32_t upM = __shfl_up(inclM, off, 64), upL = __shfl_up(inclL, off, 64);
+                    if ((int)lane >= off) { inclM += upM; inclL += upL; }
                 }
-                items = (uint32_t)__shfl((int)incl, 63, 64);
-                before = incl - extraMine;
-                uint32_t base = 0;
-                if (lane == 0u) base = atomicAdd(&ctlOut[RT_WF_CTL_EXTRA], items);
-                base = (uint32_t)__shfl((int)base, 0, 64);
-                if ((uint64_t)base + items > (uint64_t)W.extraCap) {
-                    for (uint32_t i = base + lane; i < W.extraCap; i += 64) {
+                itemsM = (uint32_t)__shfl((int)inclM, 63, 64); itemsL = (uint32_t)__shfl((int)inclL, 63, 64);
+                beforeM = inclM - extraM; beforeL = inclL - extraL;
+            }
+            const uint32_t items = itemsM + itemsL;
+            // room in region B for the wave's further segments (a wave that cuts anything: one atomic).  A reservation is never undone (an
+            // add followed by a subtract is not atomic across waves); a count past extraCap just means "region B is full", every reader
+            // clamps it; the one wave whose range straddles the end owns [at, extraCap) and marks those slots empty.  No room, no
+            // cutting: the wave's rays stay whole -- decided BEFORE the classes are counted, so that every counted entry is placed.
+            uint32_t extraBase = 0;
+            bool room = true;
+            if (items != 0u) { // wave-uniform
+                if (lane == 0u) extraBase = atomicAdd(&ctlOut[RT_WF_CTL_EXTRA], items);
+                extraBase = (uint32_t)__shfl((int)extraBase, 0, 64);
+                if ((uint64_t)extraBase + items > (uint64_t)W.extraCap) {
+                    room = false;
+                    for (uint32_t i = extraBase + lane; i < W.extraCap; i += 64) {
                         W.ent[outq][4 * (size_t)(2u * W.capacity + i)].x = 0xffffffffu;
                         W.sortRank[2u * W.capacity + i] = 0xffffffffu;
                     }
-                    if (nseg > 1u) nseg = 1u;
-                    items = 0;
+                    if (nsegM > 1u) nsegM = 1u;
+                    if (nsegL > 1u) nsegL = 1u;
                 }
-                extraAt = 2u * W.capacity + base; // region B of the entry array starts after the 2*capacity queue slots
-                // who owns item i (= further segment before + j - 1 of lane `owner`)
-                for (uint32_t j = 1; j < nseg; ++j) itemOwner[wave][before + j - 1] = (uint8_t)lane;
             }
-            if (which) { itemsL = items; itemsAtL = extraAt; } else { itemsM = items; itemsAtM = extraAt; }
-            const float ta = fminf(plan.start.dx, fminf(plan.start.dy, plan.start.dz));
-            const uint32_t perSeg = nseg ? (plan.visits + nseg - 1) / nseg : 1u;
-            if (has) { // segment 0, at the ray's queue index; where a cut ray's segment 0 ends is filled in by the lane that makes cut 1
-                float tau1;
-                const bool cut1 = nseg > 1u && cut_at(ta, plan.te, 1u, nseg, tau1);
-                const uint32_t bin = visit_class(cut1 ? perSeg : plan.visits);
-                const uint32_t rank = atomicAdd(&waveHist[wave][bin], 1u);
-                if (which) { binL = bin; rankL = rank; } else { binM = bin; rankM = rank; }
-                if (nseg > 1u) { // (.z comes from another lane: not written here, so that the two stores cannot meet)
-                    *reinterpret_cast<uint2 *>(e) = make_uint2(mine, plan.start.cell | (bin << 24));
-                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
-                } else e[0] = make_uint4(mine, plan.start.cell | (bin << 24), plan.endCell, excluded);
-                e[1] = make_uint4(__float_as_uint(plan.start.dx), __float_as_uint(plan.start.dy), __float_as_uint(plan.start.dz), __float_as_uint(tmin));
-                e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), rank); // (rank inside this wave's class for now; segment 0)
+            const uint32_t extraAt = 2u * W.capacity + extraBase; // region B of the entry array starts after the 2*capacity queue slots
+            const float taM = fminf(planM.start.dx, fminf(planM.start.dy, planM.start.dz)), taL = fminf(planL.start.dx, fminf(planL.start.dy, planL.start.dz));
+            const uint32_t perM = nsegM ? (planM.visits + nsegM - 1) / nsegM : 1u, perL = nsegL ? (planL.visits + nsegL - 1) / nsegL : 1u;
+            // classes and ranks inside the wave: segment 0 of both rays, then every further segment (whose class follows from the cut
+            // positions alone: the cuts that exist are a prefix of 1 .. nseg - 1, cut_at)
+            uint32_t binM = 0, rankM = 0, binL = 0, rankL = 0;
+            {
+                float tau;
+                if (emit) { binM = visit_class(nsegM > 1u && cut_at(taM, planM.te, 1u, nsegM, tau) ? perM : planM.visits); rankM = atomicAdd(&waveHist[wave][binM], 1u); }
+                if (emitLa) { binL = visit_class(nsegL > 1u && cut_at(taL, planL.te, 1u, nsegL, tau) ? perL : planL.visits); rankL = atomicAdd(&waveHist[wave][binL], 1u); }
+                if (cutting && room) {
+#pragma unroll 1
+                    for (int which = 0; which < 2; ++which) {
+                        const uint32_t n = which ? nsegL : nsegM, per = which ? perL : perM, visits = which ? planL.visits : planM.visits;
+                        const float ta = which ? taL : taM, te = which ? planL.te : planM.te;
+                        const uint32_t at = which ? itemsM + beforeL : beforeM;
+                        for (uint32_t k = 1; k < n; ++k) {
+                            uint32_t word = 0xffffffffu; // (cut k does not exist: no entry)
+                            if (cut_at(ta, te, k, n, tau)) {
+                                const bool cutNext = k + 1u < n && cut_at(ta, te, k + 1u, n, tau);
+                                const uint32_t bin = visit_class(cutNext ? per : visits - per * k);
+                                word = atomicAdd(&waveHist[wave][bin], 1u) | (bin << 24);
+                            }
+                            itemWord[wave][at + k - 1] = word;
+                            itemOwner[wave][at + k - 1] = (uint8_t)lane;
+                        }
+                    }
+                }
             }
-            if (items == 0u) continue; // wave-uniform
-            // The further segments, one per lane whoever's ray it is (a lane making its ray's up to 11 cuts one after the other while the
-            // wave's other lanes wait was 40 % of a chunk's time).  Segment k goes from the walk's state at tau_k to the start cell of
-            // segment k + 1; the cuts that exist are a prefix of 1 .. nseg - 1 (cut_at), so every lane can tell from k alone whether cut
-            // k and cut k + 1 exist, and writes where the segment BEFORE its own ends.
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i0 = 0; i0 < items; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                const bool liveItem = i < items;
-                const uint32_t owner = liveItem ? itemOwner[wave][i] : 0u;
-                const uint32_t k = i - (uint32_t)__shfl((int)before, owner, 64) + 1u; // this lane makes cut k of `owner`'s ray
-                const V3 po = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
-                const V3 pd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
-                const float ptmin = __shfl(tmin, owner, 64), ptmax = __shfl(tmax, owner, 64), pta = __shfl(ta, owner, 64), pte = __shfl(plan.te, owner, 64);
-                const uint32_t pexcl = __shfl(excluded, owner, 64), pmine = __shfl(mine, owner, 64), pcell = __shfl(plan.start.cell, owner, 64);
-                const uint32_t pnseg = __shfl(nseg, owner, 64), pvisits = __shfl(plan.visits, owner, 64), pend = __shfl(plan.endCell, owner, 64);
-                if (!liveItem) continue;
-                const uint32_t at = extraAt + i; // entry of segment k
-                float tau, tauNext;
-                const bool cut = cut_at(pta, pte, k, pnseg, tau);
-                const bool cutNext = k + 1u < pnseg && cut_at(pta, pte, k + 1u, pnseg, tauNext);
-                uint32_t *prev = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)(k == 1u ? pmine : at - 1u));
-                uint32_t *self = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)at);
-                if (!cut) { // rounding left no room for this cut: the segment before runs to the ray's end, this one does not exist
-                    prev[2] = pend;
-                    self[0] = 0xffffffffu;
-                    W.sortRank[at] = 0xffffffffu;
-                    continue;
-                }
-                DdaState st;
-                // (counting the crossings with T <= tau from the ray's start cell: the state does not depend on where counting begins)
-                const uint32_t nx = axis_state_at(planes, pcell & 255u, po.x, pd.x, tau, st.dx, cellLut, lutScale[0]);
-                const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (pcell >> 8) & 255u, po.y, pd.y, tau, st.dy, cellLut + 256, lutScale[1]);
-                const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), pcell >> 16, po.z, pd.z, tau, st.dz, cellLut + 512, lutScale[2]);
-                st.cell = nx | (ny << 8) | (nz << 16);
-                prev[2] = st.cell; // the segment before ends where this one starts
-                const uint32_t per = (pvisits + pnseg - 1) / pnseg;
-                const uint32_t bin = visit_class(cutNext ? per : pvisits - per * k);
-                const uint32_t rank = atomicAdd(&waveHist[wave][bin], 1u);
-                *reinterpret_cast<uint2 *>(self) = make_uint2(pmine, st.cell | (bin << 24));
-                self[3] = pexcl;
-                if (!cutNext) self[2] = pend; // the ray's last segment
-                uint4 *se = reinterpret_cast<uint4 *>(self);
-                se[1] = make_uint4(__float_as_uint(st.dx), __float_as_uint(st.dy), __float_as_uint(st.dz), __float_as_uint(ptmin));
-                se[2] = make_uint4(__float_as_uint(po.x), __float_as_uint(po.y), __float_as_uint(po.z), __float_as_uint(ptmax));
-                se[3] = make_uint4(__float_as_uint(pd.x), __float_as_uint(pd.y), __float_as_uint(pd.z), rank | (k << 24));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier(); // (itemOwner is rewritten for the look-ahead rays)
-        }
-        if (copy != 0xfffffff0u) DG(9);
-        if (ORDERED) {
-            // rank inside the (class, copy) = this wave's base + rank inside the wave: lane b fetches the base of class b (one atomic
-            // instruction for the wave's up to 64 classes).  One wave, in-order LDS: wavefront-scope fences are all the ordering needed.
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            // lane b fetches where class b's ranks of this wave start: the one returned atomic that stands between the plans and the stores
             {
                 uint32_t l2 = lane;
-                asm volatile("" : "+v"(l2)); // (the address is made here: hoisted out of the chunk loop it was spilled, and its reload waited for every store in flight)
+                asm volatile("" : "+v"(l2)); // (the address is made here: hoisted out of the chunk loop it was spilled)
                 const uint32_t n = waveHist[wave][l2];
                 waveBase[wave][l2] = n ? atomicAdd(&ctlOut[RT_WF_CTL_HIST + copy * RT_WF_SORT_BINS + l2], n) : 0u;
                 waveHist[wave][l2] = 0u; // (for this wave's next chunk)
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (emit) { W.sortRank[slot] = waveBase[wave][binM] + rankM; W.sortTag[slot] = (uint16_t)(binM | (copy << 6)); }
-            if (emitLa) { W.sortRank[slotLa] = waveBase[wave][binL] + rankL; W.sortTag[slotLa] = (uint16_t)(binL | (copy << 6)); }
+            // segment 0 of both rays, at their queue indices; where a cut ray's segment 0 ends is filled in by the lane that makes cut 1
 #pragma unroll 1
-            for (int which = 0; which < 2; ++which) { // the further segments: class and rank in the wave are in the entries
-                const uint32_t items = which ? itemsL : itemsM, at0 = which ? itemsAtL : itemsAtM;
-                for (uint32_t i = lane; i < items; i += 64) {
-                    const uint4 *se = W.ent[outq] + 4 * (size_t)(at0 + i);
-                    if (se[0].x == 0xffffffffu) continue;
-                    const uint32_t bin = se[0].y >> 24;
-                    W.sortRank[at0 + i] = waveBase[wave][bin] + (se[3].w & 0xffffffu);
-                    W.sortTag[at0 + i] = (uint16_t)(bin | (copy << 6));
+            for (int which = 0; which < 2; ++which) {
+                const bool has = which ? emitLa : emit;
+                if (!has) continue;
+                const V3 o = which ? lo3 : ro, d = which ? ld3v : rd;
+                const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
+                const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
+                const uint32_t bin = which ? binL : binM, rank = which ? rankL : rankM, cell = which ? planL.start.cell : planM.start.cell;
+                const uint32_t endCell = which ? planL.endCell : planM.endCell, nseg = which ? nsegL : nsegM;
+                uint4 *e = W.ent[outq] + 4 * (size_t)mine;
+                W.pathOf[outq][mine] = a;
+                W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
+                if (which) W.laSlot[a] = mine;
+                if (nseg > 1u) { // (.z comes from another lane: not written here, so that the two stores cannot meet)
+                    *reinterpret_cast<uint2 *>(e) = make_uint2(mine, cell);
+                    reinterpret_cast<uint32_t *>(e)[3] = excluded;
+                } else e[0] = make_uint4(mine, cell, endCell, excluded);
+                e[1] = make_uint4(__float_as_uint(which ? planL.start.dx : planM.start.dx), __float_as_uint(which ? planL.start.dy : planM.start.dy),
+                                  __float_as_uint(which ? planL.start.dz : planM.start.dz), __float_as_uint(tmin));
+                e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
+                e[3] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), 0u); // (segment 0)
+                W.sortRank[mine] = waveBase[wave][bin] + rank;
+                W.sortTag[mine] = (uint16_t)(bin | (copy << 6));
+            }
+            // The further segments, one per lane whoever's ray it is (a lane making its ray's up to 11 cuts one after the other while the
+            // wave's other lanes wait was 40 % of a chunk's time).  Segment k goes from the walk's state at tau_k to the start cell of
+            // segment k + 1; every lane can tell from k alone whether cut k and cut k + 1 exist, and writes where the segment BEFORE its
+            // own ends.
+            if (room) {
+#pragma unroll 1
+                for (int which = 0; which < 2; ++which) {
+                    // (what the lanes hand out is picked by `which`, the same for the whole wave, BEFORE the shuffles: a shuffle reads nothing
+                    // from a lane that sits the instruction out, so none of them may stand in a branch of its own)
+                    const V3 so = which ? lo3 : ro, sd = which ? ld3v : rd;
+                    const float stmin = which ? latmin : rtmin, stmax = which ? RT_INF : rtmax, sta = which ? taL : taM, ste = which ? planL.te : planM.te;
+                    const uint32_t sexcl = which ? laexcl : rexcl, smine = which ? slotLa : slot, scell = which ? planL.start.cell : planM.start.cell;
+                    const uint32_t snseg = which ? nsegL : nsegM, send = which ? planL.endCell : planM.endCell, sbefore = which ? beforeL : beforeM;
+                    const uint32_t count = which ? itemsL : itemsM, base = which ? itemsM : 0u;
+                    for (uint32_t i0 = 0; i0 < count; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        const bool liveItem = i < count;
+                        const uint32_t owner = liveItem ? itemOwner[wave][base + i] : 0u;
+                        const uint32_t word = liveItem ? itemWord[wave][base + i] : 0xffffffffu;
+                        const uint32_t k = i - (uint32_t)__shfl((int)sbefore, owner, 64) + 1u; // this lane makes cut k of `owner`'s ray
+                        const V3 po = mk(__shfl(so.x, owner, 64), __shfl(so.y, owner, 64), __shfl(so.z, owner, 64));
+                        const V3 pd = mk(__shfl(sd.x, owner, 64), __shfl(sd.y, owner, 64), __shfl(sd.z, owner, 64));
+                        const float ptmin = __shfl(stmin, owner, 64), ptmax = __shfl(stmax, owner, 64), pta = __shfl(sta, owner, 64), pte = __shfl(ste, owner, 64);
+                        const uint32_t pexcl = __shfl(sexcl, owner, 64), pmine = __shfl(smine, owner, 64), pcell = __shfl(scell, owner, 64);
+                        const uint32_t pnseg = __shfl(snseg, owner, 64), pend = __shfl(send, owner, 64);
+                        if (!liveItem) continue;
+                        const uint32_t at = extraAt + base + i; // entry of segment k
+                        uint32_t *prev = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)(k == 1u ? pmine : at - 1u));
+                        uint32_t *self = reinterpret_cast<uint32_t *>(W.ent[outq] + 4 * (size_t)at);
+                        if (word == 0xffffffffu) { // rounding left no room for this cut: the segment before runs to the ray's end, this one does not exist
+                            prev[2] = pend;
+                            self[0] = 0xffffffffu;
+                            W.sortRank[at] = 0xffffffffu;
+                            continue;
+                        }
+                        float tau, tauNext;
+                        (void)cut_at(pta, pte, k, pnseg, tau);
+                        const bool cutNext = k + 1u < pnseg && cut_at(pta, pte, k + 1u, pnseg, tauNext);
+                        DdaState st;
+                        // (counting the crossings with T <= tau from the ray's start cell: the state does not depend on where counting begins)
+                        const uint32_t nx = axis_state_at(planes, pcell & 255u, po.x, pd.x, tau, st.dx, cellLut, lutScale[0]);
+                        const uint32_t ny = axis_state_at(planes + (RT_GRID_DIV + 1), (pcell >> 8) & 255u, po.y, pd.y, tau, st.dy, cellLut + 256, lutScale[1]);
+                        const uint32_t nz = axis_state_at(planes + 2 * (RT_GRID_DIV + 1), pcell >> 16, po.z, pd.z, tau, st.dz, cellLut + 512, lutScale[2]);
+                        st.cell = nx | (ny << 8) | (nz << 16);
+                        prev[2] = st.cell; // the segment before ends where this one starts
+                        *reinterpret_cast<uint2 *>(self) = make_uint2(pmine, st.cell);
+                        self[3] = pexcl;
+                        if (!cutNext) self[2] = pend; // the ray's last segment
+                        uint4 *se = reinterpret_cast<uint4 *>(self);
+                        se[1] = make_uint4(__float_as_uint(st.dx), __float_as_uint(st.dy), __float_as_uint(st.dz), __float_as_uint(ptmin));
+                        se[2] = make_uint4(__float_as_uint(po.x), __float_as_uint(po.y), __float_as_uint(po.z), __float_as_uint(ptmax));
+                        se[3] = make_uint4(__float_as_uint(pd.x), __float_as_uint(pd.y), __float_as_uint(pd.z), k << 24);
+                        const uint32_t bin = word >> 24;
+                        W.sortRank[at] = waveBase[wave][bin] + (word & 0xffffffu);
+                        W.sortTag[at] = (uint16_t)(bin | (copy << 6));
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier(); // (waveBase is overwritten by this wave's next chunk)
+            __builtin_amdgcn_wave_barrier(); // (waveBase, itemOwner and itemWord are rewritten by this wave's next chunk)
         }
+        if (copy != 0xfffffff0u) DG(9);
         if (copy != 0xfffffff0u) DG(10);
 #ifdef RT_DIAG_LOGIC
         if (round == RT_DIAG_LOGIC) {

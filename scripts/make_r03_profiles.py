@@ -1,0 +1,112 @@
+"""Builds profiles/r03_* from one run of scripts/r03_evidence.sh (gpurun_out/r03_evidence): bench lines, rocprofv3 kernel stats and one
+frame's timeline, per-kernel counter sums per frame (fabric requests by size, L2, writes, SQ, cycles), the primary kernel's VALU-busy
+figure at 4K, the rank-share table, the RCCL world-1 test log.  usage: python scripts/make_r03_profiles.py [evidence dir]"""
+import collections, csv, glob, json, os, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03_evidence")
+dst = os.path.join(ROOT, "profiles")
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+
+
+def kname(n):
+    """wf_trace_kernel<true> etc.: the template arguments stay (the two instantiations are different kernels), the parameter list goes"""
+    n = n.strip('"')
+    if n.startswith("void "): n = n[5:]
+    return n.split("(")[0].replace(" ", "")
+
+
+def counters(tag):
+    """{kernel: {counter: sum}}, {kernel: dispatches} of one --pmc pass"""
+    sums = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    for f in glob.glob(os.path.join(src, "pmc_" + tag, "**", "*counter_collection.csv"), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if (k, r["Dispatch_Id"]) not in seen:
+                seen.add((k, r["Dispatch_Id"])); calls[k] += 1
+    return sums, calls
+
+
+for a, b in [("bench_lambert1m", "r03_bench"), ("bench_lambert_4k", "r03_bench_lambert4k"), ("bench_lambert_10m_4k", "r03_bench_lambert10m_4k"),
+             ("bench_s4", "r03_bench_s4"), ("bench_s16", "r03_bench_s16"), ("bench_primary_100k", "r03_bench_primary100k")]:
+    path = os.path.join(src, a + ".json")
+    if not os.path.exists(path) or not open(path).read().strip():
+        print("missing", a); continue
+    line = open(path).read().strip().splitlines()[-1]
+    json.loads(line)
+    open(os.path.join(dst, b + ".json"), "w").write(line + "\n")
+
+stats = glob.glob(os.path.join(src, "ktrace", "**", "*kernel_stats.csv"), recursive=True)[0]
+with open(os.path.join(dst, "r03_wavefront_lambert1m_kernel_stats.csv"), "w") as f:  # (the rocPRIM kernels' names run to kilobytes: cut)
+    for r in csv.reader(open(stats)):
+        r[0] = r[0][:160]
+        csv.writer(f).writerow(r)
+trace = glob.glob(os.path.join(src, "ktrace", "**", "*kernel_trace.csv"), recursive=True)[0]
+rows = [r for r in csv.DictReader(open(trace)) if kname(r["Kernel_Name"]).startswith(("wf_", "rt_"))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "wf_primary" in r["Kernel_Name"]]
+start = idx[len(idx) // 2]  # a frame of the timed loop (the last ones are the stage-timed frames: events between the stages)
+t0 = int(rows[start]["Start_Timestamp"])
+with open(os.path.join(dst, "r03_frame_timeline.txt"), "w") as f:
+    f.write("# one planned frame of lambert_1m (rocprofv3 --kernel-trace of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`): start offset, duration, kernel\n")
+    for r in rows[start:idx[len(idx) // 2 + 1]]:
+        f.write(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:9.1f}us  {(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:9.1f}us  {kname(r["Kernel_Name"])}\n')
+
+per = collections.defaultdict(dict)
+ea, calls = counters("ea")
+frames = calls["wf_primary_kernel"]
+hit, _ = counters("hit")
+wr, _ = counters("write")
+sq, _ = counters("sq")
+cyc, ccalls = counters("cyc")
+for k in ea:
+    if not k.startswith(("wf_", "rt_detile")): continue
+    e, h, w, s, c = ea[k], hit.get(k, {}), wr.get(k, {}), sq.get(k, {}), cyc.get(k, {})
+    cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8 / max(ccalls["wf_primary_kernel"], 1)
+    valu = c.get("SQ_INSTS_VALU", 0) * 4 / 1024 / max(ccalls["wf_primary_kernel"], 1)
+    per[k] = {"launches_per_frame": calls[k] / frames,
+              "fabric_read_requests": round(e["TCC_EA0_RDREQ_sum"] / frames), "fabric_read_bytes": round(e["TCC_EA0_RDREQ_sum"] * 128 / frames),
+              "requests_128B": round(e["TCC_EA0_RDREQ_128B_sum"] / frames), "requests_64B": round(e["TCC_EA0_RDREQ_64B_sum"] / frames),
+              "requests_32B": round(e["TCC_EA0_RDREQ_32B_sum"] / frames), "l2_requests": round(h.get("TCC_REQ_sum", 0) / frames),
+              "l2_hits": round(h.get("TCC_HIT_sum", 0) / frames), "l2_misses": round(h.get("TCC_MISS_sum", 0) / frames),
+              "write_bytes": round(w.get("WRITE_SIZE", 0) * 1024 / frames) if w.get("WRITE_SIZE", 0) < 1e9 else round(w.get("WRITE_SIZE", 0) / frames),
+              "valu_wave_instructions": round(s.get("SQ_INSTS_VALU", 0) / frames), "valu_thread_cycles": round(s.get("SQ_THREAD_CYCLES_VALU", 0) / frames),
+              "wave_cycles_x4": round(s.get("SQ_WAVE_CYCLES", 0) / frames), "wait_any_x4": round(s.get("SQ_WAIT_ANY", 0) / frames),
+              "wait_inst_any_x4": round(s.get("SQ_WAIT_INST_ANY", 0) / frames), "waves": round(s.get("SQ_WAVES", 0) / frames),
+              "kernel_cycles": round(cycles), "valu_issue_cycles_per_simd": round(valu), "valu_busy": round(valu / cycles, 3) if cycles else None,
+              "insts_salu": round(c.get("SQ_INSTS_SALU", 0) / max(ccalls["wf_primary_kernel"], 1)), "insts_lds": round(c.get("SQ_INSTS_LDS", 0) / max(ccalls["wf_primary_kernel"], 1))}
+note = ("Per kernel and frame of lambert_1m (1920x1080, 1 M triangles, S=1), summed over the kernel's launches in a frame; separate rocprofv3 --pmc passes "
+        "(scripts/r03_evidence.sh).  fabric_read_bytes = TCC_EA0_RDREQ x 128 B: every read request of these kernels is a 128-byte one (requests_32B/64B ~ 0), and "
+        "FETCH_SIZE tallies them at 64 B (the guide's x2 on gfx950).  These are requests leaving L2 towards the fabric -- HBM or the Infinity Cache, which no "
+        "exposed counter tells apart.  write_bytes = WRITE_SIZE x 1024.  kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_issue_cycles_per_simd = SQ_INSTS_VALU x 4 / "
+        "1024 SIMDs; valu_busy their ratio.  wave_cycles / wait counters are per-SE sums in units of 4 cycles.")
+json.dump({"workload": "lambert_1m", "commit": commit, "frames": frames, "note": note, "per_frame": per},
+          open(os.path.join(dst, "r03_trace_fabric_traffic.json"), "w"), indent=1)
+
+sq4, c4 = counters("sq4k")
+g4, _ = counters("grbm4k")
+if "wf_primary_kernel" in sq4:
+    f4 = c4["wf_primary_kernel"]
+    p = {k: round(v / f4) for k, v in sq4["wf_primary_kernel"].items()}
+    p.update({k: round(v / f4) for k, v in g4["wf_primary_kernel"].items()})
+    cy = p["GRBM_GUI_ACTIVE"] / 8
+    valu = p["SQ_INSTS_VALU"] / 1024 * 4
+    json.dump({"workload": "lambert_4k", "commit": commit, "kernel": "wf_primary_kernel", "per_frame": p,
+               "reading": "GRBM_GUI_ACTIVE / 8 XCDs = cycles the kernel took; SQ_INSTS_VALU / 1024 SIMDs x 4 = cycles of VALU issue per SIMD; two profiler passes",
+               "derived": {"kernel_cycles": round(cy), "valu_issue_cycles_per_simd": round(valu), "valu_busy_fraction": round(valu / cy, 3),
+                           "instructions_per_wave": round(p["SQ_INSTS_VALU"] / p["SQ_WAVES"], 1)}},
+              open(os.path.join(dst, "r03_primary_4k_valu.json"), "w"), indent=1)
+
+with open(os.path.join(dst, "r03_rank_share.txt"), "w") as f:
+    f.write("# what ONE rank of an N-rank run does per frame, rendered on one GPU (scripts/rank_share.py): rank 0's round-robin share of the 128x128 tiles, no gather.\n"
+            "# The last column bounds the N-GPU speed-up BEFORE the gather.  No multi-GPU run stands behind these numbers.\n")
+    for name in ("rank_share_1m", "rank_share_1m_s4", "rank_share_1m_s16", "rank_share_4k", "rank_share_4k_s4", "rank_share_10m_4k"):
+        path = os.path.join(src, name + ".txt")
+        if os.path.exists(path):
+            f.write("".join(l for l in open(path) if " N=" in l))
+if os.path.exists(os.path.join(src, "rccl_world1.log")):
+    shutil.copy(os.path.join(src, "rccl_world1.log"), os.path.join(dst, "r03_rccl_world1_pytest.log"))
+print("profiles/r03_* rebuilt from", src, "at", commit, "frames", frames)

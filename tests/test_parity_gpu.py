@@ -723,7 +723,7 @@ def test_dropin_cache_keeps_the_parts_an_edit_does_not_touch():
     first, p0 = check(base, "first call")
     texel = copy.copy(base)
     texel.textures = base.textures.copy()
-    texel.textures[:, :3] = 255 - texel.textures[:, :3]
+    texel.textures[:256, :3] = 255 - texel.textures[:256, :3]   # (the colour image's texels: the one-texel channels behind it stay black)
     pic, p1 = check(texel, "texture atlas changed")
     assert not np.array_equal(pic, first)
     assert p1[0] == p0[0] and p1[1] == p0[1] and p1[2] == p0[2], "geometry / grid were rebuilt for a texel edit"
