@@ -192,7 +192,8 @@ __device__ __forceinline__ unsigned long long diag_stamp()
 // GetSpherePoint (raytrace_opencl.c:30-45) split in two: the draws, and the scaling by the sphere's radius.  The number of
 // draws does not depend on the radius, so a hit's light samples can be drawn before the radius is looked at.
 struct SphereRaw { V3 p; float len, sq; };
-__device__ SphereRaw sphere_raw(uint64_t &s)
+// (forced inline: left to the inliner it became a call in the round-0 kernels once they grew, with the generator state in scratch)
+__device__ __forceinline__ SphereRaw sphere_raw(uint64_t &s)
 {
     SphereRaw r;
     do {
