@@ -129,7 +129,7 @@ def main():
         t_dev_grid = {"device_ms": round(ms, 3), "wall_s_with_transfers": round(time.time() - t0, 4)}
         del probe
     if world > 1:
-        sc = T.broadcast_scene(sc, rank, device)
+        sc = T.broadcast_scene(sc, rank, device, keep_on_device=not rehearse)  # (receiving ranks: the tensors go to the library as they are)
     W, H, P, S = sc.width, sc.height, sc.pixels, sc.sample_count
 
     my_tiles = R.tiles_of_rank(W, H, rank, world)

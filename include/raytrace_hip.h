@@ -162,6 +162,10 @@ typedef struct rtHipSceneDesc {
     const cl_int *lightType;
     const cl_float3 *lightPos, *lightDir, *lightCol;
     const cl_float *lightRadius, *lightHalfAtt;
+    cl_int    arraysOnDevice;   /* 0: every array is host memory (what RaytraceAll receives).  1: every array pointer is DEVICE memory of the
+                                 * GPU the scene is created on -- e.g. the tensors an RCCL broadcast left there -- and is copied device to
+                                 * device; only the small tables the host has to look at (split planes, material tables, texels, lights,
+                                 * one grid word) come back to it */
 } rtHipSceneDesc;
 
 typedef struct rtHipScene rtHipScene; /* opaque: a scene resident in one GPU's HBM */

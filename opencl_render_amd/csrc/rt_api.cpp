@@ -142,8 +142,17 @@ struct Stager {
         memcpy(dst, src, n / parts);
         for (auto &th : pool) th.join();
     }
+    // is `p` device memory (a scene description may hand over arrays that are already on the GPU)?
+    static bool on_device(const void *p)
+    {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; } // (plain host memory: "invalid value")
+        return at.type == hipMemoryTypeDevice;
+    }
     hipError_t copy(void *dst, const void *src, size_t bytes)
     {
+        if (bytes && on_device(src)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream); // no staging: HBM to HBM
         for (size_t off = 0; off < bytes;) {
             const size_t n = std::min(size, bytes - off);
             const int i = next;
@@ -191,6 +200,8 @@ struct rtHipScene {
     Stager stager;
     uint32_t *prepErr = nullptr;   // device word: RT_PREP_ERR_* bits raised by the validation kernels
     uint64_t camListSize = 0;
+    uint32_t gridListSizeHint = 0;  // scene description with device arrays: scenePixelTriangleListStart[256^3], fetched by scene_build
+    bool haveGridListSize = false;
     bool wfMultiLight = false;     // what the path-state buffers were sized for
     uint64_t bytes = 0;
     std::vector<cl_uint> tileIds;
@@ -442,7 +453,7 @@ int build_grid(rtHipScene *sc, const rtHipSceneDesc *d)
     }
     const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
     if (!d->gridStart) return fail("null scenePixelTriangleListStart");
-    const uint64_t listSize = d->gridStart[cells];
+    const uint64_t listSize = sc->haveGridListSize ? sc->gridListSizeHint : d->gridStart[cells]; // (the last start = the list's length; read from the device by scene_build when the array lives there)
     if (listSize && !d->gridList) return fail("null scenePixelTriangleList");
     if (sc->upload(d->gridStart, cells + 1, &D.gridStart, "gridStart")) return -1;
     if (sc->upload(d->gridList, listSize, &D.gridList, "gridList")) return -1;
@@ -710,6 +721,29 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
         fprintf(stderr, "libraytrace_hip: scene build: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tLast).count());
         tLast = now;
     };
+    // arrays that are already on the device: the few tables the host looks at itself come back to it, the rest is copied HBM to HBM
+    rtHipSceneDesc shadowed;
+    std::vector<char> hostCopies[10];
+    cl_uint gridEnd[1] = { 0 };
+    if (d->arraysOnDevice) {
+        shadowed = *d;
+        auto fetch = [&](int slot, const void *&field, size_t bytes) -> int {
+            if (!field || !bytes) return 0;
+            hostCopies[slot].resize(bytes);
+            HIP_OK(hipMemcpy(hostCopies[slot].data(), field, bytes, hipMemcpyDeviceToHost));
+            field = hostCopies[slot].data();
+            return 0;
+        };
+        const uint64_t cells = (uint64_t)RT_GRID_DIV * RT_GRID_DIV * RT_GRID_DIV;
+        if (d->gridStart) { HIP_OK(hipMemcpy(gridEnd, d->gridStart + cells, 4, hipMemcpyDeviceToHost)); sc->gridListSizeHint = gridEnd[0]; sc->haveGridListSize = true; }
+        if (fetch(0, (const void *&)shadowed.boxMin, (size_t)(RT_GRID_DIV + 1) * 16) || fetch(1, (const void *&)shadowed.matSize, (size_t)d->materialCount * 40) ||
+            fetch(2, (const void *&)shadowed.matStart, (size_t)d->materialCount * 20) || fetch(3, (const void *&)shadowed.textures, (size_t)d->texturesSize * 4) ||
+            fetch(4, (const void *&)shadowed.lightType, (size_t)d->lightCount * 4) || fetch(5, (const void *&)shadowed.lightPos, (size_t)d->lightCount * 16) ||
+            fetch(6, (const void *&)shadowed.lightDir, (size_t)d->lightCount * 16) || fetch(7, (const void *&)shadowed.lightCol, (size_t)d->lightCount * 16) ||
+            fetch(8, (const void *&)shadowed.lightRadius, (size_t)d->lightCount * 4) || fetch(9, (const void *&)shadowed.lightHalfAtt, (size_t)d->lightCount * 4))
+            return -1;
+        d = &shadowed;
+    }
     if (build_fixed(sc, d, tileIds, tileCount) != 0) return -1;
     mark("tiles, outputs, bump tables");
     if (like) {

@@ -48,6 +48,10 @@ void rtHipSetCamera(cl_float3 *outEyeToTopLeft, cl_float3 *outLeftToRight, cl_fl
     float cam[3] = { object[0] - position[0], object[1] - position[1], object[2] - position[2] };
     float side[3]; // "rightToLeft" in the reference = cross(up, cameraVector); it ends up as the LEFT-TO-RIGHT pixel vector
     crossf(up, cam, side);
+    // `(float)tan(fov / 2.f)` at render.cpp:469 is C++: with MSVC's <math.h> the call most likely resolves to the float overload, i.e.
+    // tanf of that runtime, where C would promote to double.  Which one -- and MSVCR120's tanf itself -- cannot be pinned here; the
+    // tangent is taken in double and rounded once, which is the correctly rounded float except at a rounding tie, so the two
+    // readings can differ by one ULP of midToLeft at most (parity unpinned, like the rest of the front-end).
     const float midToLeft = (float)std::sqrt((double)dotf(cam, cam)) * (float)std::tan((double)(fov / 2.f));
     const float midToTop = midToLeft * (float)height / (float)width;
     const float sideLen = (float)std::sqrt((double)dotf(side, side));

@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
             rayX[threadIdx.x] = make_uint4(excl, q, plan.start.cell, plan.endCell);
             rayT[threadIdx.x] = make_float4(plan.start.dx, plan.start.dy, plan.start.dz, plan.te);
         }
-        // one pass of 256 lanes must do: a workgroup whose rays would make more segments cuts them coarser (at most 128 + one per ray)
+        // one pass of 256 lanes must do: a workgroup whose rays would make more segments cuts them coarser
         if (wave < 2) {
             uint32_t sum = n;
 #pragma unroll
@@ -1344,7 +1344,9 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         const uint32_t all = planWave[0] + planWave[1];
         __syncthreads();
         if (wave < 2) {
-            if (all > 256u && n > 1u) n = max(1u, n * 128u / all);
+            // (every ray keeps one segment at least: what is left of the 256 lanes is shared out in proportion)
+            const uint32_t raysHere = min(group, (count - row + rowsUsed - 1u) / rowsUsed);
+            if (all > 256u && n > 1u) n = max(1u, n * (256u - raysHere) / all);
             uint32_t incl = n;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {

@@ -45,6 +45,7 @@ class SceneDesc(C.Structure):  # rtHipSceneDesc
         ("texturesSize", C.c_uint32), ("textures", C.c_void_p),
         ("lightCount", C.c_uint32), ("lightType", C.c_void_p), ("lightPos", C.c_void_p), ("lightDir", C.c_void_p), ("lightCol", C.c_void_p),
         ("lightRadius", C.c_void_p), ("lightHalfAtt", C.c_void_p),
+        ("arraysOnDevice", C.c_int32),
     ]
 
 
@@ -195,8 +196,13 @@ def last_error() -> str:
     return lib().rtHipLastError().decode("utf-8", "replace")
 
 
-def _ptr(a: Optional[np.ndarray]):
-    return None if a is None else a.ctypes.data_as(C.c_void_p)
+def _ptr(a):
+    """Address of a numpy array -- or of a torch tensor (a scene whose arrays are already on the GPU, see scene_desc)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def _f3(v) -> Float3:
@@ -343,6 +349,11 @@ def scene_desc(sc: Scene) -> SceneDesc:
     d.lightCount, d.lightType = sc.light_count, _ptr(sc.light_type)
     d.lightPos, d.lightDir, d.lightCol = _ptr(sc.light_pos), _ptr(sc.light_dir), _ptr(sc.light_col)
     d.lightRadius, d.lightHalfAtt = _ptr(sc.light_radius), _ptr(sc.light_half_att)
+    # arrays that are torch CUDA tensors (tiles.broadcast_scene(keep_on_device=True)): the library copies them HBM to HBM
+    on_device = [bool(getattr(getattr(sc, k), "is_cuda", False)) for k in ("vertex", "tri_index", "cam_start", "grid_start", "textures", "light_type")]
+    if any(on_device) and not all(on_device):
+        raise ValueError("a scene's arrays must be all host arrays or all device tensors")
+    d.arraysOnDevice = 1 if all(on_device) else 0
     return d
 
 

@@ -84,11 +84,17 @@ _ARRAY_FIELDS = ["eye", "eye_to_top_left", "left_to_right", "top_to_bottom", "ve
                  "light_radius", "light_half_att", "cam_start", "cam_end", "cam_list", "box_min", "grid_start", "grid_list"]
 
 
-def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=None, rebuild_on_root: bool = False) -> Scene:
+_TORCH_DTYPES = {"<f4": torch.float32, "<i4": torch.int32, "<u4": torch.uint32, "|u1": torch.uint8}
+
+
+def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=None, rebuild_on_root: bool = False,
+                    keep_on_device: bool = False) -> Scene:
     """Rank 0 holds the scene (and its lists); every other rank receives a copy.  Arrays travel as byte tensors on
     `device` -- over xGMI with the nccl backend -- instead of every rank rebuilding or re-reading them
     ('upload once via root then broadcast').  `rebuild_on_root`: rank 0 too returns a scene made from the
-    broadcast tensors instead of the one it was given (tests: the bytes that travelled are the bytes that are used)."""
+    broadcast tensors instead of the one it was given (tests: the bytes that travelled are the bytes that are used).
+    `keep_on_device` (nccl only): a receiving rank's scene holds the broadcast tensors themselves, viewed in their dtypes --
+    ResidentScene then hands the library device pointers (rtHipSceneDesc::arraysOnDevice) and nothing bounces through host memory."""
     head = [None]
     if rank == 0:
         scalars = dict(width=sc.width, height=sc.height, pixel_size_inv=sc.pixel_size_inv, sample_count=sc.sample_count,
@@ -110,7 +116,12 @@ def broadcast_scene(sc: Optional[Scene], rank: int, device: torch.device, group=
         if nbytes:
             dist.broadcast(t, src=0, group=group)
         keep = rank == 0 and not rebuild_on_root
-        arrays[k] = getattr(sc, k) if keep else t.cpu().numpy().view(np.dtype(dtype)).reshape(shape).copy()
+        if keep:
+            arrays[k] = getattr(sc, k)
+        elif keep_on_device and t.is_cuda:
+            arrays[k] = t.view(_TORCH_DTYPES[np.dtype(dtype).str]).reshape(shape)
+        else:
+            arrays[k] = t.cpu().numpy().view(np.dtype(dtype)).reshape(shape).copy()
         del t
     if rank == 0 and not rebuild_on_root:
         return sc

@@ -2,7 +2,7 @@
 
 ``oracle()``   -> oracle/liboracle.so, the repo's C restatement of the reference's C path.
 ``ref()``      -> oracle/_ref/libref_kernel.so, the reference's own kernel file compiled in place (only present where
-                  it was built from /root/reference, i.e. the build container; it ships prebuilt to the GPU box).
+                  it was built from /root/reference, i.e. in the build container; on a GPU box the golden fixtures minted from it stand in).
 """
 from __future__ import annotations
 

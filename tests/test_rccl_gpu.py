@@ -46,8 +46,11 @@ def test_frame_through_broadcast_gather_and_detile_on_rccl(rccl_world1, name):
     device = rccl_world1
     assert dist.get_backend() == "nccl"
     sc0, want = load_golden_scene(name)
-    sc = T.broadcast_scene(sc0, 0, device, rebuild_on_root=True)   # object list + one device byte tensor per array, over RCCL
-    assert sc is not sc0 and np.array_equal(sc.vertex, sc0.vertex) and np.array_equal(sc.grid_list, sc0.grid_list)
+    # object list + one device byte tensor per array, over RCCL; the scene keeps the tensors (as a receiving rank of bench.py does) and the
+    # library copies them HBM to HBM (rtHipSceneDesc::arraysOnDevice)
+    sc = T.broadcast_scene(sc0, 0, device, rebuild_on_root=True, keep_on_device=True)
+    assert sc is not sc0 and sc.vertex.is_cuda and sc.grid_start.is_cuda and sc.vertex.shape == sc0.vertex.shape
+    assert np.array_equal(sc.vertex.cpu().numpy(), sc0.vertex) and np.array_equal(sc.grid_list.cpu().numpy().view(np.uint32), sc0.grid_list)
     W, H, P = sc.width, sc.height, sc.pixels
     world, rank = 1, 0
     rs = R.ResidentScene(sc, 0, R.tiles_of_rank(W, H, rank, world))
