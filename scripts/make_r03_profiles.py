@@ -48,11 +48,16 @@ trace = glob.glob(os.path.join(src, "ktrace", "**", "*kernel_trace.csv"), recurs
 rows = [r for r in csv.DictReader(open(trace)) if kname(r["Kernel_Name"]).startswith(("wf_", "rt_"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "wf_primary" in r["Kernel_Name"]]
-start = idx[len(idx) // 2]  # a frame of the timed loop (the last ones are the stage-timed frames: events between the stages)
+# a planned frame of the timed loop: the shortest of the run's frames (watched frames, the frames with a copy to the host and the stage-timed
+# frames with events between their kernels are all longer)
+spans = [(int(rows[idx[j + 1] - 1]["End_Timestamp"]) - int(rows[idx[j]]["Start_Timestamp"]), j) for j in range(len(idx) - 1)
+         if not any("rt_trace_kernel" in r["Kernel_Name"] for r in rows[idx[j]:idx[j + 1]])]
+pick = min(spans)[1]
+start = idx[pick]
 t0 = int(rows[start]["Start_Timestamp"])
 with open(os.path.join(dst, "r03_frame_timeline.txt"), "w") as f:
     f.write("# one planned frame of lambert_1m (rocprofv3 --kernel-trace of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`): start offset, duration, kernel\n")
-    for r in rows[start:idx[len(idx) // 2 + 1]]:
+    for r in rows[start:idx[pick + 1]]:
         f.write(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:9.1f}us  {(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:9.1f}us  {kname(r["Kernel_Name"])}\n')
 
 per = collections.defaultdict(dict)
