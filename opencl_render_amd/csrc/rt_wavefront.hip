@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     const char *__restrict__ blockTable = reinterpret_cast<const char *>(S.gridBlockSparse);
     const char *planeBytes = reinterpret_cast<const char *>(planes);
 
-    uint32_t wordKey = 0xffffffffu, wordLo = 0, wordHi = 0; // occupancy word of the last block looked up (key = cell & 0xFCFCFC)
+    uint32_t wordKey = 0xffffffffu, wordLo = 0, wordHi = 0, wordRank = 0; // occupancy word + rank of the last block looked up (key = cell & 0xFCFCFC)
     uint32_t listed = 0;
     bool walkEnded = !active;
     uint32_t spins = 0;
@@ -1502,18 +1502,19 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 for (int u = 0; u < RT_WF_BLIND; ++u) { RT_WALK_STEP(false) }
             }
 #undef RT_WALK_STEP
-            // look-up: which of the logged cells are occupied?  Keep those, in path order, at the front of the list.  Only the
+            // look-up: which of the logged cells are occupied?  Keep those -- as their DENSE ids, which is what the test phase gathers
+            // records by -- in path order, at the front of the list.  Only the
             // requested words stay in registers across the wait; the logged cells are read back from LDS on both sides of it
             // (what a word is needed for -- "the block differs from the one before" -- is recomputed the same way).
-            uint2 lw[RT_WF_BLIND];
+            uint3 lw[RT_WF_BLIND];
             {
                 uint32_t prev = wordKey;
 #pragma unroll
                 for (int i = 0; i < RT_WF_BLIND; ++i) {
-                    lw[i] = make_uint2(0u, 0u);
+                    lw[i] = make_uint3(0u, 0u, 0u);
                     if ((uint32_t)i < logged) {
                         const uint32_t key = cellList[listed + i][threadIdx.x] & 0xFCFCFCu;
-                        if (key != prev) { lw[i] = *reinterpret_cast<const uint2 *>(blockTable + (size_t)(key * 3u)); prev = key; }
+                        if (key != prev) { lw[i] = *reinterpret_cast<const uint3 *>(blockTable + (size_t)(key * 3u)); prev = key; }
                     }
                 }
             }
@@ -1523,12 +1524,15 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 if ((uint32_t)i < logged) {
                     const uint32_t c = cellList[listedBefore + i][threadIdx.x]; // slot listedBefore + i >= listed: not overwritten yet
                     const uint32_t key = c & 0xFCFCFCu;
-                    if (key != wordKey) { wordKey = key; wordLo = lw[i].x; wordHi = lw[i].y; }
+                    if (key != wordKey) { wordKey = key; wordLo = lw[i].x; wordHi = lw[i].y; wordRank = lw[i].z; }
                     // bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 : gather the three 2-bit fields with one multiply
                     const uint32_t bit = (((c & 0x030303u) * 0x1041u) >> 12) & 63u;
                     const uint32_t half = (c & 0x20000u) ? wordHi : wordLo; // bit 5 of `bit` is bit 1 of cz
                     if ((half >> (bit & 31u)) & 1u) {
-                        cellList[listed][threadIdx.x] = c;
+                        // the cell's dense id = rank of its block + occupied cells below it in the block: what the test phase gathers by
+                        const uint32_t below = (1u << (bit & 31u)) - 1u;
+                        const uint32_t inLo = __popc(wordLo & ((c & 0x20000u) ? 0xffffffffu : below));
+                        cellList[listed][threadIdx.x] = wordRank + inLo + ((c & 0x20000u) ? __popc(wordHi & below) : 0u);
                         ++listed;
                     }
                 }
@@ -1592,12 +1596,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                     if (has) {
                         const uint32_t j = c - ownerBase;
                         const uint32_t pc = cellList[j][(wave << 6) + owner];
-                        // dense cell id = rank of the block + occupied cells below this one in the block
-                        const uint32_t *gb = reinterpret_cast<const uint32_t *>(blockTable + (size_t)((pc & 0xFCFCFCu) * 3u));
-                        const uint32_t lo32 = gb[0], hi32 = gb[1], rank = gb[2];
-                        const uint32_t bit = (pc & 3u) | ((pc >> 6) & 12u) | ((pc >> 12) & 48u);
-                        const unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;
-                        const uint32_t dense = rank + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+                        const uint32_t dense = pc; // (made by the look-up that found the cell occupied)
                         const float4 *rec = reinterpret_cast<const float4 *>(S.pairRec) + 4 * (size_t)dense;
                         float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                         const uint32_t info = __float_as_uint(r1.w);
