@@ -1205,8 +1205,10 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(const RtWavefront W, co
 //   * per-ray constants of the step are precomputed per axis (signed cell increment, plane-table offset, exit coordinate);
 //   * the occupancy word of a 4x4x4 block is found at byte offset 3*(cell & 0xFCFCFC) of a sparsely indexed copy of the
 //     block table (two instructions instead of six: rt_device.h, gridBlockSparse), its bit with one multiply (bit-gather) and one bit-field extract;
-//   * an occupied cell is recorded as its packed coordinates only; the dense cell id (rank + popcount) is worked out in the
-//     test phase, where all 64 lanes have an item, instead of in the walk, where 6 of 64 lanes are on an occupied cell.
+//   * an occupied cell is recorded as its DENSE id (rank of its block, which arrives with the occupancy word, + occupied cells below
+//     it): the index the test phase gathers the cell's record by.  Working it out in the test phase, where all 64 lanes have an item,
+//     costs fewer instructions (6 of 64 lanes are on an occupied cell in the walk) but a second dependent gather of the block word
+//     per item: one round trip per item instead of two was worth 5 % of the kernel (round 3).
 #ifndef RT_WF_LEAN_WAVES
 #define RT_WF_LEAN_WAVES 5
 #endif
