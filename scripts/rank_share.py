@@ -16,9 +16,13 @@ sc = bench.make_scene(wl, samples)
 base = None
 for n in ns:
     rs = R.ResidentScene(sc, 0, R.tiles_of_rank(sc.width, sc.height, 0, n) if n > 1 else None)
-    for _ in range(3):
-        rs.render()
-    rs.sync()
+    # (the chip needs ~20 ms of continuous work to reach its steady clocks from idle -- scripts/x_ramp.py; ranks of a real run render
+    # frame after frame, so the share is timed on a busy chip)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.06:
+        for _ in range(5):
+            rs.render()
+        rs.sync()
     t0 = time.perf_counter()
     k = 30 if sc.pixels * samples < 20_000_000 else 8
     for _ in range(k):

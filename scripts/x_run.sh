@@ -1,3 +1,5 @@
 export TMPDIR=/tmp
-bash scripts/x_multi.sh prev base early prev base early
-SHARE=8 bash scripts/x_multi.sh prev base early
+bash scripts/x_multi.sh base base
+WORKLOAD=lambert_4k bash scripts/x_multi.sh base
+SHARE=8 bash scripts/x_multi.sh base
+timeout -k 10 600 python3 -m pytest tests/test_parity_gpu.py -x -q -m gpu > gpurun_out/x_pytest.log 2>&1; tail -3 gpurun_out/x_pytest.log
