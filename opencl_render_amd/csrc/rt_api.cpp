@@ -122,14 +122,35 @@ struct Stager {
     bool used[2] = { false, false };
     size_t size = 0;
     int next = 0;
+    // Pinning 2 x 32 MB costs 15-25 ms, more than the rest of an instance's build when its shared parts are copied from another
+    // instance: the buffers are taken when the first host array needs them and go back to a process-wide pool, not to the driver.
+    struct Pool {
+        std::mutex lock;
+        std::vector<std::pair<char *, size_t>> idle;
+        char *take(size_t bytes)
+        {
+            {
+                std::lock_guard<std::mutex> g(lock);
+                for (size_t i = 0; i < idle.size(); ++i)
+                    if (idle[i].second == bytes) { char *p = idle[i].first; idle.erase(idle.begin() + i); return p; }
+            }
+            char *p = nullptr;
+            if (hipHostMalloc((void **)&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            return p;
+        }
+        void give(char *p, size_t bytes)
+        {
+            std::lock_guard<std::mutex> g(lock);
+            if (idle.size() < 8) idle.emplace_back(p, bytes);
+            else (void)hipHostFree(p);
+        }
+    };
+    static Pool &pool() { static Pool *p = new Pool(); return *p; } // (never destroyed: buffers may come back during process exit)
     int init(hipStream_t st)
     {
         stream = st;
         size = (size_t)std::min<uint32_t>(std::max<uint32_t>(tuning().stageMb, 1u), 4096u) << 20;
-        for (int i = 0; i < 2; ++i) {
-            HIP_OK(hipHostMalloc((void **)&buf[i], size, hipHostMallocDefault));
-            HIP_OK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-        }
+        for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         return 0;
     }
     static void fill(char *dst, const char *src, size_t n)
@@ -158,6 +179,7 @@ struct Stager {
             const int i = next;
             next ^= 1;
             if (used[i]) { const hipError_t e = hipEventSynchronize(done[i]); if (e != hipSuccess) return e; }
+            if (!buf[i] && !(buf[i] = pool().take(size))) return hipErrorOutOfMemory;
             fill(buf[i], (const char *)src + off, n);
             hipError_t e = hipMemcpyAsync((char *)dst + off, buf[i], n, hipMemcpyHostToDevice, stream);
             if (e != hipSuccess) return e;
@@ -168,17 +190,19 @@ struct Stager {
         }
         return hipSuccess;
     }
-    hipError_t drain()
+    hipError_t drain() // every copy so far has left its staging buffer; the buffers go back to the pool (the next instance's build takes them)
     {
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
             if (used[i]) { const hipError_t e = hipEventSynchronize(done[i]); if (e != hipSuccess) return e; used[i] = false; }
+            if (buf[i]) { pool().give(buf[i], size); buf[i] = nullptr; }
+        }
         return hipSuccess;
     }
     void destroy()
     {
         for (int i = 0; i < 2; ++i) {
             if (done[i]) { if (used[i]) (void)hipEventSynchronize(done[i]); (void)hipEventDestroy(done[i]); done[i] = nullptr; }
-            if (buf[i]) { (void)hipHostFree(buf[i]); buf[i] = nullptr; }
+            if (buf[i]) { pool().give(buf[i], size); buf[i] = nullptr; }
         }
     }
 };
@@ -766,6 +790,7 @@ int scene_build(rtHipScene *sc, const rtHipSceneDesc *d, const cl_uint *tileIds,
     // what only a kernel can tell about the inputs (ids inside the lists): one look at the error word
     HIP_OK(rtp_validate(sc->dev.triangleCount, 0, 0, nullptr, nullptr, sc->camListSize, sc->dev.camList, nullptr, 0, nullptr, sc->prepErr, sc->stream));
     HIP_OK(hipStreamSynchronize(sc->stream));
+    HIP_OK(sc->stager.drain()); // (the stream is idle: the staging buffers go back to the pool)
     if (sc->check_prep() != 0) return -1;
     if (build_wavefront(sc, d->sampleCount) != 0) return -1;
     refresh_views(sc);

@@ -1,5 +1,2 @@
 export TMPDIR=/tmp
-bash scripts/x_multi.sh base base
-WORKLOAD=lambert_4k bash scripts/x_multi.sh base
-SHARE=8 bash scripts/x_multi.sh base
-timeout -k 10 600 python3 -m pytest tests/test_parity_gpu.py -x -q -m gpu > gpurun_out/x_pytest.log 2>&1; tail -3 gpurun_out/x_pytest.log
+timeout -k 10 300 python3 scripts/x_four.py > gpurun_out/x_four.log 2>&1; tail -60 gpurun_out/x_four.log

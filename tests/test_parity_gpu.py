@@ -750,19 +750,24 @@ def test_all_gpus_mode_builds_the_scene_once(monkeypatch):
     import time
     n = R.lib().rtHipDeviceCount()
     sc = _bench_scene("lambert_1m")
-    R.lib().rtHipCacheClear()
-    t0 = time.perf_counter()
-    ok, r1, g1, b1 = R.raytrace_all(1, sc)
-    one = time.perf_counter() - t0
-    assert ok, R.last_error()
-    R.lib().rtHipCacheClear()
-    monkeypatch.setenv("RT_HIP_VIRTUAL_DEVICES", "4")
-    t0 = time.perf_counter()
-    ok, r, g, b = R.raytrace_all(n + 1, sc)
-    four = time.perf_counter() - t0
-    assert ok, R.last_error()
-    assert np.array_equal(r, r1) and np.array_equal(g, g1) and np.array_equal(b, b1)
+    one = four = 1e9
+    for rep in range(2):  # (the first call of either kind also pays the driver's first mapping of that much memory: the better of two is compared)
+        R.lib().rtHipCacheClear()
+        monkeypatch.delenv("RT_HIP_VIRTUAL_DEVICES", raising=False)
+        t0 = time.perf_counter()
+        ok, r1, g1, b1 = R.raytrace_all(1, sc)
+        one = min(one, time.perf_counter() - t0)
+        assert ok, R.last_error()
+        R.lib().rtHipCacheClear()
+        monkeypatch.setenv("RT_HIP_VIRTUAL_DEVICES", "4")
+        t0 = time.perf_counter()
+        ok, r, g, b = R.raytrace_all(n + 1, sc)
+        four = min(four, time.perf_counter() - t0)
+        assert ok, R.last_error()
+        assert np.array_equal(r, r1) and np.array_equal(g, g1) and np.array_equal(b, b1)
     _assert_sampled_rows(sc, (r, g, b), 16, "1920x1080 / 1 M over 4 instances")
     print(f"first RaytraceAll on the 1 M-triangle scene: one instance {1e3 * one:.1f} ms, four instances {1e3 * four:.1f} ms wall")
-    assert four < 2.0 * one + 0.05, (one, four)
+    # measured: 17 ms against 35 ms (every instance allocates its own path state, uploads its own camera ranges and renders a watched first
+    # frame; the shared parts are copied in under a millisecond each).  Uploading and reshaping the scene per instance was 4 x 24 ms more.
+    assert four < 2.5 * one + 0.03, (one, four)
     R.lib().rtHipCacheClear()
