@@ -178,6 +178,13 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def drained():
+        """torch.cuda.synchronize() behind a poll of the frame's stream: the runtime's blocking wait has been seen to return tens of
+        milliseconds after the device finished (interrupt-driven wake-ups on a shared host), which a 19 ms timed region cannot absorb."""
+        while not work_stream.query():
+            pass
+        torch.cuda.synchronize()
+
     # ORDER: everything that is not the contract's W + K frames runs FIRST -- the watched-frame figure, the stage-timed and counted
     # passes, the frames with copies to the host -- and the timed region comes last.  The chip takes ~20 ms of continuous work to reach
     # its steady clocks from idle (scripts/x_ramp.py: frames 1-10 of a cold start 0.996 ms, 11-20 0.946, from then on 0.922-0.927): timed
@@ -229,7 +236,7 @@ def main():
     t1 = time.perf_counter()
     for _ in range(args.steps):
         frame(host_planes)
-    torch.cuda.synchronize()
+    drained()
     barrier()
     ms_with_d2h = 1e3 * (time.perf_counter() - t1) / args.steps
     serial_ref = host_planes.clone() if rank == 0 else None  # what the serial frames left in host memory (the pipelined ones reuse the buffer)
@@ -264,7 +271,10 @@ def main():
     t2 = time.perf_counter()
     for i in range(args.steps):
         frame_pipelined(i + DEPTH)
-    torch.cuda.synchronize()
+    if rank == 0:
+        while not copy_stream.query():
+            pass
+    drained()
     barrier()
     ms_with_d2h_pipelined = 1e3 * (time.perf_counter() - t2) / args.steps
     if rank == 0 and not all(torch.equal(h, serial_ref) for h in host2):
@@ -281,6 +291,11 @@ def main():
     stage_ms = {k: v / stage_frames for k, v in stage_ms.items()}
     rs.stage_timing(False)
     # ---- the contract's region: W warm-up frames, then K timed frames between barriers --------------------------------------
+    # (the interpreter's cyclic garbage collector is held off meanwhile: a full collection with torch imported walks a few hundred
+    # thousand objects -- tens of milliseconds of a host thread that has 19 ms of frames to keep the device fed with)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         frame()
     torch.cuda.synchronize()
@@ -290,9 +305,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
-    torch.cuda.synchronize()
+    drained()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     # The timed frames were issued from a launch plan, without looking at the ray queue (rtHipFrameFinish): now that the
     # device is idle, check that every one of them really was complete.  A frame that was not voids the run.
     if rs.finish():

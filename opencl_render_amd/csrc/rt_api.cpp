@@ -246,6 +246,7 @@ struct rtHipScene {
         uint32_t logicBlocks = 1, traceBlocks = 1, queueBlocks = 1;
         uint32_t *hostCount = nullptr;  // pinned: queue length read back between round chunks
         uint32_t *hostStatus = nullptr; // pinned + mapped: RT_WF_STATUS_* words the kernels write (rt_device.h)
+        bool ctlClean = false;          // the batch before was a planned one: wf_status_kernel left the control words zeroed
         uint32_t rounds = 0;
         uint32_t slot0 = 0, slot1 = 0;  // this group's range of the instance's tile slots
         // launch plan (render_wavefront): what the last discovery frame needed
@@ -934,13 +935,15 @@ int render_wavefront(rtHipScene *sc, hipStream_t st, bool forceDiscovery)
             G.rounds = 0;
             G.modes.clear();
             G.guessRays = (uint64_t)(G.slot1 - G.slot0) * RT_TILE_PIXELS * G.wf.samplesInBatch; // round 1 of a watched batch: as if every pixel were a path
-            HIP_OK(hipMemsetAsync(G.wf.ctl, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_CTL_WORDS, on));
+            if (!G.ctlClean) HIP_OK(hipMemsetAsync(G.wf.ctl, 0, sizeof(uint32_t) * (size_t)3 * RT_WF_CTL_WORDS, on));
+            G.ctlClean = false;
             if (!planned) memset(G.hostLog, 0, sizeof(uint4) * RT_WF_ROUND_LOG); // (nothing of this group is in flight: the batch before was waited for)
             HIP_OK(stage(0, on, [&] { return rtw_launch_primary(&G.dev, &G.wf, on); }));
             if (planned) {
                 while (G.rounds < planRounds)
                     if (issue_round(G, on) != 0) return -1;
                 HIP_OK(rtw_launch_status(&G.wf, G.rounds, on));
+                G.ctlClean = true;
             } else if (issue_chunk(G, on) != 0) return -1;
         }
         for (size_t g = 0; g < sc->groups.size(); ++g) {

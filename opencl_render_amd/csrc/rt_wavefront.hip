@@ -1727,6 +1727,9 @@ __global__ __launch_bounds__(256) void wf_status_kernel(const RtWavefront W, con
         if (waiting) atomicAdd(W.hostStatus + RT_WF_STATUS_WAITING, waiting);
         atomicAdd(W.hostStatus + RT_WF_STATUS_BATCHES, 1u);
     }
+    // nothing of the batch is in flight any more: leave all three sets of control words zeroed for the next one (the host skips its memset --
+    // a launch of the runtime's fill kernel with ~6 us of idle time in front of it -- when the batch before ended here)
+    for (uint32_t i = threadIdx.x; i < 3u * RT_WF_CTL_WORDS; i += 256u) W.ctl[i] = 0u;
 }
 
 // ---- launch wrappers ------------------------------------------------------------------------------------------------
