@@ -185,6 +185,12 @@ def main():
             pass
         torch.cuda.synchronize()
 
+    # The interpreter's cyclic garbage collector is held off from here to the end of the timed region: a full collection with torch
+    # imported walks a few hundred thousand objects -- tens of milliseconds of a host thread that has 19 ms of frames to keep the device
+    # fed with (and a collection right in front of the timed frames would let the chip's clocks drop again).
+    import gc
+    gc.collect()
+    gc.disable()
     # ORDER: everything that is not the contract's W + K frames runs FIRST -- the watched-frame figure, the stage-timed and counted
     # passes, the frames with copies to the host -- and the timed region comes last.  The chip takes ~20 ms of continuous work to reach
     # its steady clocks from idle (scripts/x_ramp.py: frames 1-10 of a cold start 0.996 ms, 11-20 0.946, from then on 0.922-0.927): timed
@@ -277,8 +283,6 @@ def main():
     drained()
     barrier()
     ms_with_d2h_pipelined = 1e3 * (time.perf_counter() - t2) / args.steps
-    if rank == 0 and not all(torch.equal(h, serial_ref) for h in host2):
-        sys.exit("bench.py: pipelined frames differ from the serial ones")
     if rs.finish():
         sys.exit("bench.py: a frame with a copy to the host needed more rounds than its launch plan issued")
     # ---- un-timed: per-stage device time (HIP events around every launch; the launches of a frame no longer run back to back) ----
@@ -291,11 +295,6 @@ def main():
     stage_ms = {k: v / stage_frames for k, v in stage_ms.items()}
     rs.stage_timing(False)
     # ---- the contract's region: W warm-up frames, then K timed frames between barriers --------------------------------------
-    # (the interpreter's cyclic garbage collector is held off meanwhile: a full collection with torch imported walks a few hundred
-    # thousand objects -- tens of milliseconds of a host thread that has 19 ms of frames to keep the device fed with)
-    import gc
-    gc.collect()
-    gc.disable()
     for _ in range(args.warmup):
         frame()
     torch.cuda.synchronize()
@@ -309,6 +308,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    # (host-side comparison of the pipelined pass's buffers, kept out of the device's way until now)
+    if rank == 0 and not all(torch.equal(h, serial_ref) for h in host2):
+        sys.exit("bench.py: pipelined frames differ from the serial ones")
     # The timed frames were issued from a launch plan, without looking at the ray queue (rtHipFrameFinish): now that the
     # device is idle, check that every one of them really was complete.  A frame that was not voids the run.
     if rs.finish():
