@@ -642,9 +642,9 @@ int build_wavefront(rtHipScene *sc, uint32_t sampleCount)
         if (sc->alloc<unsigned long long>(cap, &Wf.rng) || sc->alloc<uint4>(cap, &Wf.meta) || sc->alloc<float4>(cap, &Wf.outc) ||
             sc->alloc<float4>(cap * RT_RING * 3, &Wf.ring) || sc->alloc<float4>(cap, &Wf.shP) || sc->alloc<float4>(cap, &Wf.shFace) ||
             sc->alloc<float4>(cap, &Wf.shAtt) || sc->alloc<float4>(multiLight ? cap : 1, &Wf.shN) ||
-            sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<unsigned long long>(cap, &Wf.laKey) || sc->alloc<uint32_t>(cap, &Wf.laSlot) ||
-            sc->alloc<uint4>(ecap * 4, &Wf.ent[0]) || sc->alloc<uint4>(ecap * 4, &Wf.ent[1]) || sc->alloc<uint32_t>(qcap, &Wf.pathOf[0]) ||
-            sc->alloc<uint32_t>(qcap, &Wf.pathOf[1]) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey[0]) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey[1]) ||
+            sc->alloc<unsigned long long>(multiLight ? cap : 1, &Wf.rngL) || sc->alloc<unsigned long long>(cap, &Wf.laKey) ||
+            sc->alloc<uint4>(ecap * 4, &Wf.ent[0]) || sc->alloc<uint4>(ecap * 4, &Wf.ent[1]) || sc->alloc<uint2>(cap, &Wf.pathOf[0]) ||
+            sc->alloc<uint2>(cap, &Wf.pathOf[1]) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey[0]) || sc->alloc<unsigned long long>(qcap, &Wf.hitKey[1]) ||
             sc->alloc<uint4>(cap, &Wf.res) || sc->alloc<float4>(gpix * sb, &Wf.sampleOut) ||
             sc->alloc<uint32_t>(ecap, &Wf.sortRank) || sc->alloc<uint16_t>(ecap, &Wf.sortTag) || sc->alloc<uint32_t>(ecap, &Wf.sortedIdx) ||
             sc->alloc<uint32_t>((uint64_t)3 * RT_WF_CTL_WORDS, &Wf.ctl))

@@ -162,7 +162,6 @@ struct RtWavefront {
     uint4 *meta;             // x: output slot (localPixel*samplesInBatch + sb)  y: localPixel  w: hit triangle
                              // z: head | tail<<4 | stage<<8 | attenuation stored<<9 | look-ahead state<<10 | look-ahead ring index<<12 | light<<16
     unsigned long long *laKey; // answer (hitKey) of the path's look-ahead ray while it waits to be consumed
-    uint32_t *laSlot;        // queue index of the look-ahead entry issued last round
     float4 *outc;            // accumulated colour xyz
     float4 *ring;            // [capacity][12][3] the pixel's ray queue (:459-468): o.xyz,tmin | d.xyz,excluded | weight.xyz, bounces<<1|fromCamera;
                              // slot `head` is the ray in flight
@@ -182,7 +181,7 @@ struct RtWavefront {
     // a path born into shard b appends to slice b % slices, so appends hit up to 512 different counters (a single address sustains
     // only ~90 atomics/us) and a slice can never overflow: it holds at most the paths of its shards.
     uint4 *ent[2];             // [2*capacity + extraCap][4], by round parity
-    uint32_t *pathOf[2];       // [2*capacity] path id of queue entry q, by round parity
+    uint2 *pathOf[2];          // [capacity] main queue entry q -> {path id, queue index of the look-ahead entry sent out with it or ~0}, by round parity
     unsigned long long *hitKey[2]; // [2*capacity] per ray: segment << 32 | pair index of the hit in the lowest segment that has one; all ones = no hit
     uint4 *res;                // round 0 only: the primary hit of the path -- triangle, t, l1, l2 (float bits)
     uint32_t shardCap;         // paths per shard (multiple of 256); capacity = RT_WF_SHARDS * shardCap

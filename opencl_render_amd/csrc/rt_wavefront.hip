@@ -565,15 +565,19 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
             // where they are used (a spill reload in this kernel is a wait for everything in flight).
             uint32_t res_tri = RT_NONE;
             float res_t = 0.f, res_l1 = 0.f, res_l2 = 0.f;
-            unsigned long long key = ~0ull;
+            unsigned long long key = ~0ull, laKeyEarly = ~0ull;
             float4 qo = make_float4(0.f, 0.f, 0.f, 0.f), qd = qo;
             if (FIRST) {
                 a = q; // (a path is born at its own round-0 queue index)
                 const uint4 r = W.res[q];
                 res_tri = r.x; res_t = __uint_as_float(r.y); res_l1 = __uint_as_float(r.z); res_l2 = __uint_as_float(r.w);
             } else {
-                a = W.pathOf[in][q];
+                // {path, queue slot of the look-ahead ray it sent out with this one}: the second answer is asked for right here, one
+                // round trip earlier than through the path's own state (it is only USED if the path's flags say it is outstanding)
+                const uint2 who = W.pathOf[in][q];
+                a = who.x;
                 key = W.hitKey[in][q];
+                if (who.y != 0xffffffffu) laKeyEarly = W.hitKey[in][who.y];
             }
             float4 *ringA = W.ring + (size_t)a * (RT_RING * 3);
             uint64_t rng = W.rng[a];
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
             uint32_t j = meta.z >> 16;
             DG(1);
             bool laFetched = false;
-            if (laState == 1u) { laKey = W.hitKey[in][W.laSlot[a]]; laState = 2u; laFetched = true; }
+            if (laState == 1u) { laKey = laKeyEarly; laState = 2u; laFetched = true; }
             else if (laState == 2u) laKey = W.laKey[a];
 
             // the ray in flight (ring slot `head`), loaded when its answer is here
@@ -895,9 +899,8 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
                 const float tmin = which ? latmin : rtmin, tmax = which ? RT_INF : rtmax;
                 const uint32_t excluded = which ? laexcl : rexcl, mine = which ? slotLa : slot;
                 uint4 *e = W.ent[outq] + 4 * (size_t)mine;
-                W.pathOf[outq][mine] = a;
+                if (!which) W.pathOf[outq][mine] = make_uint2(a, emitLa ? slotLa : 0xffffffffu); // (only main entries are ever looked up: wf_logic_kernel's prologue)
                 W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
-                if (which) W.laSlot[a] = mine;
                 reinterpret_cast<uint32_t *>(e)[3] = excluded;
                 reinterpret_cast<uint32_t *>(e)[7] = __float_as_uint(tmin);
                 e[2] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(tmax));
@@ -1026,9 +1029,8 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
                 const uint32_t bin = which ? binL : binM, rank = which ? rankL : rankM, cell = which ? planL.start.cell : planM.start.cell;
                 const uint32_t endCell = which ? planL.endCell : planM.endCell, nseg = which ? nsegL : nsegM;
                 uint4 *e = W.ent[outq] + 4 * (size_t)mine;
-                W.pathOf[outq][mine] = a;
+                if (!which) W.pathOf[outq][mine] = make_uint2(a, emitLa ? slotLa : 0xffffffffu); // (only main entries are ever looked up: wf_logic_kernel's prologue)
                 W.hitKey[outq][mine] = ~0ull; // no segment of this ray has a hit yet
-                if (which) W.laSlot[a] = mine;
                 if (nseg > 1u) { // (.z comes from another lane: not written here, so that the two stores cannot meet)
                     *reinterpret_cast<uint2 *>(e) = make_uint2(mine, cell);
                     reinterpret_cast<uint32_t *>(e)[3] = excluded;

@@ -1,2 +1,4 @@
 export TMPDIR=/tmp
-timeout -k 10 600 python3 scripts/x_soak.py > gpurun_out/x_soak.log 2>&1; tail -8 gpurun_out/x_soak.log
+bash scripts/x_multi.sh base base
+SHARE=8 bash scripts/x_multi.sh base
+timeout -k 10 600 python3 -m pytest tests/test_parity_gpu.py -x -q -m gpu > gpurun_out/x_pytest.log 2>&1; tail -3 gpurun_out/x_pytest.log
