@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, FIRST ? (ORDERED ? RT_WF_LOGIC_WAVES_FIRST_ORD
             int head = (int)(meta.z & 15u), tail = (int)((meta.z >> 4) & 15u);
             const uint32_t stage = (meta.z >> 8) & 1u;
             bool attStored = ((meta.z >> 9) & 1u) != 0u;
-            uint32_t laState = (meta.z >> 10) & 3u; // 0 none, 1 requested last round (answer at res[laSlot]), 2 answer kept in laRes
+            uint32_t laState = (meta.z >> 10) & 3u; // 0 none, 1 requested last round (answer at hitKey[pathOf.y]), 2 answer kept in laKey
             int laIndex = (int)((meta.z >> 12) & 15u);
             uint32_t j = meta.z >> 16;
             DG(1);

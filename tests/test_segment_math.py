@@ -1,4 +1,4 @@
-"""CPU restatement of the property the trace kernel's ray SEGMENTATION rests on (rt_wavefront.hip, wf_setup_kernel):
+"""CPU restatement of the property the trace kernel's ray SEGMENTATION rests on (rt_wavefront.hip: plan_ray, segments_of, cut_at, axis_state_at):
 
 The reference's grid walk (raytrace_opencl.c:383-398) is a 3-way merge of per-axis plane-crossing parameters
 T_a(i) = (plane_a[i] - o_a) / d_a, evaluated in float32 exactly as the reference does.  Per axis the sequence is
@@ -79,7 +79,7 @@ def test_counted_state_equals_walked_state(seed):
         if seed % 2:  # some axis-dominant rays: long runs on one axis, many equal-looking heads
             d[rng.integers(0, 3)] *= F(50.0)
         steps = list(walk(planes, o, d, start))
-        # exit parameter as wf_setup_kernel computes it
+        # exit parameter as plan_ray computes it
         te = min(F(F(planes[a, DIV if d[a] >= 0 else 0] - o[a]) / d[a]) for a in range(3))
         ta = min(steps[0][1])
         if not (np.isfinite(te) and np.isfinite(ta) and ta < te):
