@@ -1515,11 +1515,13 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 uint32_t prev = wordKey;
 #pragma unroll
                 for (int i = 0; i < RT_WF_BLIND; ++i) {
-                    lw[i] = make_uint3(0u, 0u, 0u);
-                    if ((uint32_t)i < logged) {
-                        const uint32_t key = cellList[listed + i][threadIdx.x] & 0xFCFCFCu;
-                        if (key != prev) { lw[i] = *reinterpret_cast<const uint3 *>(blockTable + (size_t)(key * 3u)); prev = key; }
-                    }
+                    // EVERY lane loads: a lane that needs no word (its block is the one it has, or it logged fewer cells) reads the table's
+                    // first entry -- one address for all of them, one access -- instead of sitting a branch out: no branch, and no
+                    // registers to zero for the lanes that skipped it (six moves per slot; -2 % of the kernel)
+                    const uint32_t key = cellList[listed + i][threadIdx.x] & 0xFCFCFCu;
+                    const bool need = ((uint32_t)i < logged) & (key != prev);
+                    lw[i] = *reinterpret_cast<const uint3 *>(blockTable + (size_t)(need ? key * 3u : 0u));
+                    prev = need ? key : prev;
                 }
             }
             const uint32_t listedBefore = listed;
