@@ -1425,8 +1425,11 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
     // per-axis step constants (:387-398): direction of travel is fixed per ray
     const bool px = (0.f <= d.x), py = (0.f <= d.y), pz = (0.f <= d.z);
     const uint32_t stepX = px ? 1u : (uint32_t)-1, stepY = py ? (1u << 8) : (uint32_t)-(1 << 8), stepZ = pz ? (1u << 16) : (uint32_t)-(1 << 16);
-    // byte offset into `planes` of the plane that bounds the NEW cell ahead: 4*(axisBase + c + (positive ? 1 : 0))
-    const uint32_t offX = 4u * (px ? 1u : 0u), offY = 4u * ((RT_GRID_DIV + 1) + (py ? 1u : 0u)), offZ = 4u * (2 * (RT_GRID_DIV + 1) + (pz ? 1u : 0u));
+    // byte offset into `planes` of the plane that bounds the NEW cell ahead, counted from the OLD cell's coordinate c (which the exit test
+    // has just extracted): the new cell is c +- 1 and its far plane c + 2 going up, c - 1 going down -> 4*(axisBase + (positive ? 2 : -1)),
+    // in wrapping 32-bit arithmetic (c >= 1 when going down: c == 0 ended the walk)
+    const uint32_t offX = 4u * (px ? 2u : (uint32_t)-1), offY = 4u * ((RT_GRID_DIV + 1) + (py ? 2u : (uint32_t)-1)),
+                   offZ = 4u * (2 * (RT_GRID_DIV + 1) + (pz ? 2u : (uint32_t)-1));
     const char *__restrict__ blockTable = reinterpret_cast<const char *>(S.gridBlockSparse);
     const char *planeBytes = reinterpret_cast<const char *>(planes);
 
@@ -1479,11 +1482,12 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                         const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);                                                         \
                         const uint32_t stepSel = sxm ? stepX : (sym ? stepY : stepZ);                                               \
                         /* the step would leave the grid (:389,:393,:397): coordinate 255 going up, 0 going down */                 \
-                        done = (((cell >> shift) & 255u) == (((int32_t)stepSel > 0) ? 255u : 0u));                                  \
+                        const uint32_t coord = (cell >> shift) & 255u;                                                              \
+                        done = (coord == (((int32_t)stepSel > 0) ? 255u : 0u));                                                     \
                         if (!done) {                                                                                                \
                             cell += stepSel;                                                                                        \
                             const uint32_t off = sxm ? offX : (sym ? offY : offZ);                                                  \
-                            const float plane = *reinterpret_cast<const float *>(planeBytes + (((cell >> shift) & 255u) << 2) + off); \
+                            const float plane = *reinterpret_cast<const float *>(planeBytes + (uint32_t)((coord << 2) + off));      \
                             const float dd = sxm ? d.x : (sym ? d.y : d.z);                                                         \
                             const float oo = sxm ? o.x : (sym ? o.y : o.z);                                                         \
                             float nd;                                                                                               \
