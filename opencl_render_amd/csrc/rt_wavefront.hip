@@ -1473,30 +1473,28 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                 if (canWalk && !walkEnded) {                                                                                        \
                     cellList[listed + logged][threadIdx.x] = cell;                                                                  \
                     ++logged;                                                                                                       \
-                    /* the end cell ends the walk after it has been visited (:380-381) */                                           \
-                    bool done = (cell == endCell);                                                                                  \
+                    /* axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z */                     \
+                    const bool sxm = (dx < dy) & (dx < dz);                                                                         \
+                    const bool sym = !sxm & (dy < dz);                                                                              \
+                    const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);                                                             \
+                    const uint32_t stepSel = sxm ? stepX : (sym ? stepY : stepZ);                                                   \
+                    const uint32_t coord = (cell >> shift) & 255u;                                                                  \
+                    /* the end cell ends the walk after it has been visited (:380-381); so does a step that would leave the grid  */ \
+                    /* (:389,:393,:397): coordinate 255 going up, 0 going down.  ONE condition, one branch: nested, the compiler   */ \
+                    /* carried "cell is the end cell" through three register moves per step                                         */ \
+                    const bool done = (cell == endCell) | (coord == (((int32_t)stepSel > 0) ? 255u : 0u));                          \
                     if (!done) {                                                                                                    \
-                        /* axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z */                 \
-                        const bool sxm = (dx < dy) & (dx < dz);                                                                     \
-                        const bool sym = !sxm & (dy < dz);                                                                          \
-                        const uint32_t shift = sxm ? 0u : (sym ? 8u : 16u);                                                         \
-                        const uint32_t stepSel = sxm ? stepX : (sym ? stepY : stepZ);                                               \
-                        /* the step would leave the grid (:389,:393,:397): coordinate 255 going up, 0 going down */                 \
-                        const uint32_t coord = (cell >> shift) & 255u;                                                              \
-                        done = (coord == (((int32_t)stepSel > 0) ? 255u : 0u));                                                     \
-                        if (!done) {                                                                                                \
-                            cell += stepSel;                                                                                        \
-                            const uint32_t off = sxm ? offX : (sym ? offY : offZ);                                                  \
-                            const float plane = *reinterpret_cast<const float *>(planeBytes + (uint32_t)((coord << 2) + off));      \
-                            const float dd = sxm ? d.x : (sym ? d.y : d.z);                                                         \
-                            const float oo = sxm ? o.x : (sym ? o.y : o.z);                                                         \
-                            float nd;                                                                                               \
-                            if (FAST) {                                                                                             \
-                                const float rr = sxm ? rx : (sym ? ry : rz);                                                        \
-                                nd = tame_quotient(plane - oo, dd, rr);                                                             \
-                            } else nd = (plane - oo) / dd;                                                                          \
-                            dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;                                     \
-                        }                                                                                                           \
+                        cell += stepSel;                                                                                            \
+                        const uint32_t off = sxm ? offX : (sym ? offY : offZ);                                                      \
+                        const float plane = *reinterpret_cast<const float *>(planeBytes + (uint32_t)((coord << 2) + off));          \
+                        const float dd = sxm ? d.x : (sym ? d.y : d.z);                                                             \
+                        const float oo = sxm ? o.x : (sym ? o.y : o.z);                                                             \
+                        float nd;                                                                                                   \
+                        if (FAST) {                                                                                                 \
+                            const float rr = sxm ? rx : (sym ? ry : rz);                                                            \
+                            nd = tame_quotient(plane - oo, dd, rr);                                                                 \
+                        } else nd = (plane - oo) / dd;                                                                              \
+                        dx = sxm ? nd : dx; dy = sym ? nd : dy; dz = (sxm | sym) ? dz : nd;                                         \
                     }                                                                                                               \
                     walkEnded = done;                                                                                               \
                 }
