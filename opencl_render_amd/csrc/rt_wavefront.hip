@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
             // when all of its rays are tame; the reciprocals live in registers only while the wave walks.
 #define RT_WALK_STEP(FAST)                                                                                                          \
                 if (canWalk && !walkEnded) {                                                                                        \
-                    cellList[listed + logged][threadIdx.x] = cell;                                                                  \
+                    cellList[listed + u][threadIdx.x] = cell; /* (a lane that walks step u has walked every step before it: logged == u) */ \
                     ++logged;                                                                                                       \
                     /* axis choice (:387-398): x only if strictly smallest, else y if smaller than z, else z */                     \
                     const bool sxm = (dx < dy) & (dx < dz);                                                                         \
@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
                     // bit (cx&3) | (cy&3)<<2 | (cz&3)<<4 : gather the three 2-bit fields with one multiply
                     const uint32_t bit = (((c & 0x030303u) * 0x1041u) >> 12) & 63u;
                     const uint32_t half = (c & 0x20000u) ? wordHi : wordLo; // bit 5 of `bit` is bit 1 of cz
-                    if ((half >> (bit & 31u)) & 1u) {
+                    if (__builtin_amdgcn_ubfe(half, bit & 31u, 1u)) {
                         // the cell's dense id = rank of its block + occupied cells below it in the block: what the test phase gathers by
                         const uint32_t below = (1u << (bit & 31u)) - 1u;
                         const uint32_t inLo = __popc(wordLo & ((c & 0x20000u) ? 0xffffffffu : below));
