@@ -1,4 +1,2 @@
 export TMPDIR=/tmp
-bash scripts/x_multi.sh prev ak prev ak prev ak
-WORKLOAD=lambert_4k bash scripts/x_multi.sh prev ak
-timeout -k 10 600 python3 -m pytest tests/test_parity_gpu.py -x -q -m gpu > gpurun_out/x_pytest.log 2>&1; tail -3 gpurun_out/x_pytest.log
+bash scripts/run_diag_trace.sh
