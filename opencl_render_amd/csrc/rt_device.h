@@ -51,8 +51,8 @@ struct RtDevScene {
     //                     block is 3*(cell & 0xFCFCFC) for a cell packed cx | cy<<8 | cz<<16 (two instructions):
     //                     50 MB of address space, 3 MiB of touched lines
     //   dense cell id     k = rank + popcount(word & ((1<<bit)-1)), bit = (cx&3) | (cy&3)<<2 | (cz&3)<<4
-    //   pairRec[i]        64-byte record of a (cell, triangle) pair: {a.xyz, triangleId} {n.xyz, count} {ab.xyz, abab} {ac.xyz, acac}
-    //                     (abac and 1/(abac^2-abab*acac) are recomputed in the test).  Records [0, cellCount) are the FIRST
+    //   pairRec[i]        64-byte record of a (cell, triangle) pair: {a.xyz, triangleId} {n.xyz, count} {ab.xyz, abac} {ac.xyz, 1/(abac^2-abab*acac)}
+    //                     (dot(ab,ab) and dot(ac,ac) are recomputed in the test).  Records [0, cellCount) are the FIRST
     //                     candidate of cell k at index k itself, `count` = candidates of the cell: a cell visit is ONE
     //                     dependent gather (the typical cell of a fine scene holds one triangle), where a {first, last} range
     //                     table in between cost a second 128-byte fabric request per visit (profiles/r02_*: the trace kernel

@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256) void rt_gather_pair_records(uint32_t pairCount
     float4 *out = pairRec + (size_t)pair * 4;
     out[0] = make_float4(r0.x, r0.y, r0.z, __uint_as_float(tri)); // a, triangle id
     out[1] = make_float4(r2.y, r2.z, r2.w, __uint_as_float(pairInfo[pair])); // n, candidates of the cell (first records only)
-    out[2] = make_float4(r0.w, r1.x, r1.y, r3.x);                  // ab, abab
-    out[3] = make_float4(r1.z, r1.w, r2.x, r3.z);                  // ac, acac
+    out[2] = make_float4(r0.w, r1.x, r1.y, r3.y);                  // ab, dot(ab,ac)
+    out[3] = make_float4(r1.z, r1.w, r2.x, r3.w);                  // ac, 1/(abac^2 - abab*acac)
 }
 
 // ---- launch wrappers (called from rt_api.cpp; keep every <<< >>> in this translation unit) -----------------------

@@ -151,8 +151,11 @@ __device__ __forceinline__ bool pair_test_flat(const float4 r0, const float4 r1,
     const V3 ao = sub3(o, a);
     t = -dot3(n, ao) / dot3(n, d);
     const V3 ab = mk(r2.x, r2.y, r2.z), ac = mk(r3.x, r3.y, r3.z);
-    const float abab = r2.w, abac = dot3(ab, ac), acac = r3.w; // dot(ab,ac) as at raytrace_opencl.c:147
-    const float inv = 1.f / (abac * abac - abab * acac);
+    // The record's two spare words carry dot(ab,ac) and 1/(abac^2 - abab*acac) as rt_prepare_triangles worked them out (:147-149, the same
+    // correctly rounded division); the two squared lengths are worked out here from the same operands.  (The other way round -- lengths
+    // stored, the quotient taken here -- was a second full division per candidate: ~13 issue slots against 10 plain ones.)
+    const float abab = dot3(ab, ab), abac = r2.w, acac = dot3(ac, ac);
+    const float inv = r3.w;
     const V3 ap = sub3(along(o, t, d), a);
     const float ap_ab = dot3(ap, ab);
     const float ap_ac = dot3(ap, ac);
