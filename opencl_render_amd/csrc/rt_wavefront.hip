@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(256, RT_WF_LEAN_WAVES) void wf_trace_kernel(const R
         // one per lane afterwards (7 % of the cells of a fine scene have any: looping over them cell by cell ran 64-lane
         // instructions for a handful of lanes, behind two more dependent gathers).  The owner re-evaluates the winning pair.
         {
-            wordKey = 0xffffffffu; // the cached occupancy word is not carried across the test phase (three registers at the kernel's peak)
+            // (the cached block entry stays across the test phase: a register or two more at the kernel's peak, one gather fewer per batch and lane)
             const uint32_t mineN = listed;
             uint32_t incl = mineN;
 #pragma unroll
